@@ -1,0 +1,146 @@
+/*
+ * piehip.h -- C ABI of libpiehip.so: the MI355X (gfx950) implementation of the server-side
+ * batched-FHE private-indexed-equality evaluation of SAP/nested-hashing-psi.
+ *
+ * Drop-in boundary.  The reference operator is the concrete class
+ *     class BatchedFHEHIPPIE            src/Common/Crypto/PrivateIndexedEqualityCheck/BatchedFHEHIPPIE.hpp:18-49
+ * constructed at src/Server/FHE/BatchedFHEPSIServer.cpp:86 and driven at :101-103,108 in the order
+ * setMinusCompareElement, setIndex, run, getResultList.  Every arithmetic instruction of run()
+ * (BatchedFHEHIPPIE.cpp:88-129) is an OpenFHE call on lbcrypto::Ciphertext<DCRTPoly> /
+ * lbcrypto::Plaintext objects; a DCRTPoly is L contiguous uint64_t[N] limbs ("towers") in
+ * EVALUATION format, so the ABI below sees only such limb arrays: plain pointers and sizes, no
+ * OpenFHE, no torch types.  INTEGRATION.md shows the binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every array is uint64_t, C-contiguous, limb-major [..][limb][N], residues canonical in
+ *     [0, modulus); ciphertext/plaintext/key polynomials are in EVALUATION (NTT, bit-reversed) format,
+ *     exactly as OpenFHE stores them after Encrypt / MakePackedPlaintext+SetFormat(EVALUATION).
+ *   - every function returns 0 on success or a negative PIEHIP_E* code and never throws;
+ *     piehip_last_error() gives the text (thread-local).  The C++ facade converts codes back into
+ *     the exception types the reference throws (BatchedFHEHIPPIE.cpp:13-21: std::invalid_argument).
+ *   - a handle is not thread-safe: one host thread per handle, as the reference uses one
+ *     BatchedFHEHIPPIE per server process (BatchedFHEPSIServer.hpp:23).
+ *   - host pointers are copied on load/set; *_device variants take pointers to HBM the caller owns
+ *     (they must stay valid until the next run() has completed).
+ */
+#ifndef PIEHIP_H
+#define PIEHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIEHIP_OK 0
+#define PIEHIP_EINVAL (-1)   /* bad argument (reference: std::invalid_argument) */
+#define PIEHIP_ESTATE (-2)   /* call order violated (run before keys/DB/inputs are set) */
+#define PIEHIP_EHIP (-3)     /* HIP runtime error (no device, allocation, launch) */
+#define PIEHIP_ENOMEM (-4)
+
+typedef struct piehip_ctx *piehip_handle;
+
+int piehip_version(void);
+const char *piehip_last_error(void);
+
+/* Default RNS chain: the largest primes < 2^60 that are 1 mod 2N, descending -- L for Q, then L+1
+ * more for the auxiliary basis P of the HPS multiplication (what GenCryptoContext derives for the
+ * reference at src/Client/FHE/BatchedFHEPSIClient.cpp:72-78). */
+int piehip_default_moduli(uint32_t N, uint32_t L, uint64_t *q /*[L]*/, uint64_t *p /*[L+1]*/);
+
+/* Replaces the CryptoContext reference held at BatchedFHEHIPPIE.hpp:21 (cryptoContext member):
+ * ring dimension N, L primes q (basis Q), L+1 primes p (basis P; NULL,NULL = default chain),
+ * plaintext modulus t (GetPlaintextModulus, BatchedFHEHIPPIE.cpp:43).
+ * device: HIP device ordinal; stream: a hipStream_t to enqueue on, or NULL for a private stream. */
+int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const uint64_t *q, const uint64_t *p,
+                  int device, void *stream);
+int piehip_destroy(piehip_handle h);
+
+/* parameter read-back (moduli: q_0..q_{L-1}, p_0..p_L, t = 2L+2 entries) */
+int piehip_get_moduli(piehip_handle h, uint64_t *out);
+int piehip_get_root(piehip_handle h, uint32_t mod_index, uint64_t *psi);
+int piehip_get_twiddles(piehip_handle h, uint32_t mod_index, uint64_t *fwd /*[N]*/, uint64_t *inv /*[N]*/);
+int piehip_get_slot_positions(piehip_handle h, uint32_t *pos /*[N]*/);
+
+/* Replaces the EvalMult key the context holds after DeserializeEvalMultKey
+ * (src/Server/FHE/BatchedFHEPSIServer.cpp:49): BV key, one digit per RNS limb,
+ * evk[L digits][2 (b,a)][L limbs][N]. */
+int piehip_load_relin_key(piehip_handle h, const uint64_t *evk);
+
+/* Replaces the constructor's packed database (BatchedFHEHIPPIE.cpp:37-82):
+ *   pts   [K][b][E][L][N]  vectorizedHCT      (BatchedFHEHIPPIE.hpp:23), EVALUATION format
+ *   masks [b][L][N]        preCalcRandomMask  (BatchedFHEHIPPIE.hpp:27)
+ * b is the number of bin layers THIS handle evaluates (a shard of the reference's eachBinSize). */
+int piehip_load_db(piehip_handle h, uint32_t K, uint32_t b, uint32_t E, const uint64_t *pts, const uint64_t *masks);
+/* Same, from raw slot values: the device performs MakePackedPlaintext (BatchedFHEHIPPIE.cpp:68,81):
+ *   slots [K][b][E][B] int64 (negative = t-|v|), mask_slots [b][B]; B <= N slots used. */
+int piehip_load_db_slots(piehip_handle h, uint32_t K, uint32_t b, uint32_t E, uint32_t B, const int64_t *slots,
+                         const int64_t *mask_slots);
+
+/* setIndex (BatchedFHEHIPPIE.hpp:40-43): idx[K][E][2][L][N];
+ * setMinusCompareElement (BatchedFHEHIPPIE.hpp:45-48): minus[2][L][N]. */
+int piehip_set_index(piehip_handle h, const uint64_t *idx);
+int piehip_set_minus(piehip_handle h, const uint64_t *minus);
+int piehip_set_index_device(piehip_handle h, const void *d_idx);
+int piehip_set_minus_device(piehip_handle h, const void *d_minus);
+
+/* run() (BatchedFHEHIPPIE.cpp:88-129): enqueue the whole evaluation on the handle's stream.
+ * Asynchronous; piehip_sync() or piehip_get_results() waits for it. */
+int piehip_run(piehip_handle h);
+int piehip_sync(piehip_handle h);
+/* getResultList (BatchedFHEHIPPIE.hpp:35-38): out[b][2][L][N] */
+int piehip_get_results(piehip_handle h, uint64_t *out);
+/* device address of the result buffer [b][2][L][N] (valid until destroy); for the RCCL gather */
+int piehip_results_device(piehip_handle h, void **d_out);
+
+/* ---- the OpenFHE primitives under run(), exposed one by one for kernel-level parity tests ------
+ * (host buffers in, host buffers out; synchronous) */
+/* DCRTPoly::SetFormat on nlimbs limbs [nlimbs][N]; limb i uses modulus mod_base + (i % mod_count) */
+int piehip_ntt(piehip_handle h, uint64_t *limbs, uint32_t nlimbs, uint32_t mod_base, uint32_t mod_count, int inverse);
+/* EvalAdd(ct,ct) BatchedFHEHIPPIE.cpp:112,116 / EvalMult(ct,pt) :108,113,126 */
+int piehip_eval_add(piehip_handle h, const uint64_t *x, const uint64_t *y, uint64_t *out);
+int piehip_eval_mult_plain(piehip_handle h, const uint64_t *x, const uint64_t *pt, uint64_t *out);
+/* EvalMult(ct,ct) BatchedFHEHIPPIE.cpp:123 (HPS P-over-Q tensor + BV relinearisation with the loaded
+ * key); nct independent pairs x[nct][2][L][N], y[nct][2][L][N] -> out[nct][2][L][N].
+ * relin=0 returns the 3-component tensor result out[nct][3][L][N] instead. */
+int piehip_eval_mult(piehip_handle h, const uint64_t *x, const uint64_t *y, uint32_t nct, int relin, uint64_t *out);
+/* EvalAtIndex-style rotation (reference call sites FHEHIPPIE.cpp:71,74 via EvalInnerProduct/EvalMerge;
+ * NOT on the batched path): automorphism X -> X^g then key switch with rk[L][2][L][N] */
+int piehip_eval_automorph(piehip_handle h, const uint64_t *x, uint32_t g, const uint64_t *rk, uint64_t *out);
+/* MakePackedPlaintext for npt plaintexts: slots[npt][B] -> out[npt][L][N] EVALUATION format */
+int piehip_encode(piehip_handle h, const int64_t *slots, uint32_t npt, uint32_t B, uint64_t *out);
+/* base conversions of the HPS multiplication on npoly polynomials (COEFFICIENT format):
+ * which = 0: Q -> QP centred extension        in[npoly][L][N]    -> out[npoly][2L+1][N]
+ * which = 1: scale by P/Q into P, extend to QP in[npoly][L][N]    -> out[npoly][2L+1][N]
+ * which = 2: scale by t/P from QP into Q      in[npoly][2L+1][N] -> out[npoly][L][N] */
+int piehip_base_convert(piehip_handle h, int which, const uint64_t *in, uint32_t npoly, uint64_t *out);
+
+/* ---- measurement ------------------------------------------------------------------------------
+ * With profiling on, run() brackets every kernel launch with HIP events on the handle's stream.
+ * piehip_profile_read returns, per kernel class, the launch count, total milliseconds, and the
+ * algorithmic bytes (SURVEY.md 8d formulas) of the last run. */
+#define PIEHIP_NKERNELS 12
+enum {
+    PIEHIP_K_STAGE_A = 0,   /* fused ct x pt multiply-accumulate + minus add  (A3+A4)          */
+    PIEHIP_K_NTT_FWD = 1,   /* forward negacyclic NTT                          (A1)             */
+    PIEHIP_K_NTT_INV = 2,   /* inverse negacyclic NTT                          (A1)             */
+    PIEHIP_K_EXPAND = 3,    /* Q->QP extension and P/Q scaling                 (A6)             */
+    PIEHIP_K_TENSOR = 4,    /* tensor product over QP                          (A5 step 4)      */
+    PIEHIP_K_SCALE = 5,     /* scale-and-round by t/P                          (A6)             */
+    PIEHIP_K_DIGITS = 6,    /* BV digit decomposition                          (A7)             */
+    PIEHIP_K_RELIN = 7,     /* key-switch multiply-accumulate (+ mask multiply) (A7, A3)        */
+    PIEHIP_K_MASK = 8,      /* final ct x pt mask multiply when not fused                       */
+    PIEHIP_K_ENCODE = 9,    /* packed encoding                                 (A2)             */
+    PIEHIP_K_AUTOMORPH = 10,/* automorphism permutation                        (A9)             */
+    PIEHIP_K_OTHER = 11
+};
+int piehip_set_profiling(piehip_handle h, int on);
+int piehip_profile_read(piehip_handle h, uint32_t *launches /*[NKERNELS]*/, double *ms /*[NKERNELS]*/,
+                        double *alg_bytes /*[NKERNELS]*/);
+const char *piehip_kernel_name(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

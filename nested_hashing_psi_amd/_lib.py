@@ -1,0 +1,65 @@
+"""ctypes loader for libpiehip.so.  Fails loudly when the HIP library is missing -- the product
+has no CPU path."""
+import ctypes as C
+import os
+
+from .build import LIB_PATH
+
+u64p = C.POINTER(C.c_uint64)
+i64p = C.POINTER(C.c_int64)
+u32p = C.POINTER(C.c_uint32)
+f64p = C.POINTER(C.c_double)
+
+NKERNELS = 12
+
+# every symbol include/piehip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "piehip_version": (C.c_int, []),
+    "piehip_last_error": (C.c_char_p, []),
+    "piehip_kernel_name": (C.c_char_p, [C.c_int]),
+    "piehip_default_moduli": (C.c_int, [C.c_uint32, C.c_uint32, u64p, u64p]),
+    "piehip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_uint64, u64p, u64p, C.c_int, C.c_void_p]),
+    "piehip_destroy": (C.c_int, [C.c_void_p]),
+    "piehip_get_moduli": (C.c_int, [C.c_void_p, u64p]),
+    "piehip_get_root": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
+    "piehip_get_twiddles": (C.c_int, [C.c_void_p, C.c_uint32, u64p, u64p]),
+    "piehip_get_slot_positions": (C.c_int, [C.c_void_p, u32p]),
+    "piehip_load_relin_key": (C.c_int, [C.c_void_p, u64p]),
+    "piehip_load_db": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, u64p, u64p]),
+    "piehip_load_db_slots": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, i64p, i64p]),
+    "piehip_set_index": (C.c_int, [C.c_void_p, u64p]),
+    "piehip_set_minus": (C.c_int, [C.c_void_p, u64p]),
+    "piehip_set_index_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "piehip_set_minus_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "piehip_run": (C.c_int, [C.c_void_p]),
+    "piehip_sync": (C.c_int, [C.c_void_p]),
+    "piehip_get_results": (C.c_int, [C.c_void_p, u64p]),
+    "piehip_results_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "piehip_ntt": (C.c_int, [C.c_void_p, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
+    "piehip_eval_add": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "piehip_eval_mult_plain": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "piehip_eval_mult": (C.c_int, [C.c_void_p, u64p, u64p, C.c_uint32, C.c_int, u64p]),
+    "piehip_eval_automorph": (C.c_int, [C.c_void_p, u64p, C.c_uint32, u64p, u64p]),
+    "piehip_encode": (C.c_int, [C.c_void_p, i64p, C.c_uint32, C.c_uint32, u64p]),
+    "piehip_base_convert": (C.c_int, [C.c_void_p, C.c_int, u64p, C.c_uint32, u64p]),
+    "piehip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "piehip_profile_read": (C.c_int, [C.c_void_p, u32p, f64p, f64p]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libpiehip.so is not built (%s). Run nested_hashing_psi_amd.build(); "
+                "there is no CPU fallback for the PIE hot path." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)  # AttributeError if the library does not export it
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib

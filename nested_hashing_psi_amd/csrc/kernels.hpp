@@ -1,0 +1,54 @@
+// kernels.hpp -- launch wrappers of the gfx950 kernels behind the C ABI (include/piehip.h).
+// Every wrapper only enqueues on `st`; none allocates or synchronises (graph-capturable).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "params.hpp"
+
+namespace piehip {
+
+// Device-resident NTT tables: for modulus a, tables + a*4*N holds tw | tw_sh | itw | itw_sh (N each).
+struct NttPlan {
+    const u64 *tables;
+    const DevConsts *dc;  // device pointer
+    u32 N, logN;
+};
+
+// In-place negacyclic NTT over `nlimbs` limbs [nlimbs][N]; limb i uses modulus mod_base + i % mod_count.
+// (replaces DCRTPoly::SetFormat under BatchedFHEHIPPIE.cpp:123)
+void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, hipStream_t st);
+
+// Stage A: acc[b][K][2][L][N] = sum_j idx[h][j] (.) db[h][beta][j] + minus    (BatchedFHEHIPPIE.cpp:101-116)
+void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
+                    const u64 *db, u64 *acc, hipStream_t st);
+
+// Base conversions, COEFFICIENT format.  Polynomial (o, c), o < n_outer, c < 2,
+// is read at in + o*in_stride_outer + c*in_stride_inner ([L][N] limbs) and written to
+// out + ((o*out_polys + out_slot + c)*M)*N ([M][N] limbs).
+void launch_expand_q_to_qp(const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t in_stride_outer,
+                           size_t in_stride_inner, u32 n_outer, u64 *out, u32 out_polys, u32 out_slot, hipStream_t st);
+void launch_scale_pq_expand(const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t in_stride_outer,
+                            size_t in_stride_inner, u32 n_outer, u64 *out, u32 out_polys, u32 out_slot, hipStream_t st);
+// e[nb][4][M][N] (a0 a1 b0 b1, EVALUATION) -> d[nb][3][M][N]
+void launch_tensor(const DevConsts *dc, u32 N, u32 M, const u64 *e, u64 *d, u32 nb, hipStream_t st);
+// d[nb][3][M][N] (COEFFICIENT) -> components 0,1 to out01 + bin*stride01 + c*L*N, component 2 to out2 + bin*stride2
+void launch_scale_round(const DevConsts *dc, u32 N, u32 L, const u64 *d, u32 nb, u64 *out01, size_t stride01, u64 *out2,
+                        size_t stride2, hipStream_t st);
+// BV digits: d2c at d2 + bin*stride2 ([L][N], COEFFICIENT) -> dig[nb][L(i)][L(j)][N] (centred lift of residue i into q_j)
+void launch_digits(const DevConsts *dc, u32 N, u32 L, const u64 *d2, size_t stride2, u32 nb, u64 *dig, hipStream_t st);
+// out[bin][c][j] = (d01[bin][c][j] + sum_i dig[bin][i][j] (.) key[i][c][j]) (.) mask[bin][j]   (mask may be null)
+void launch_relin_mac(const DevConsts *dc, u32 N, u32 L, const u64 *d01, size_t stride01, const u64 *dig, const u64 *key,
+                      const u64 *mask, u64 *out, u32 nb, hipStream_t st);
+// element-wise helpers on nct ciphertexts [nct][2][L][N]
+void launch_ct_add(const DevConsts *dc, u32 N, u32 L, const u64 *x, const u64 *y, u64 *out, u32 nct, hipStream_t st);
+void launch_ct_mul_plain(const DevConsts *dc, u32 N, u32 L, const u64 *x, const u64 *pt, size_t pt_stride, u64 *out,
+                         u32 nct, hipStream_t st);
+// out[r][p] = in[r][map[p]] for nrows limbs
+void launch_permute(u32 N, const u64 *in, const u32 *map, u64 *out, u32 nrows, hipStream_t st);
+// packed encoding: slots[npt][B] -> u[npt][N] residues mod t at their EVALUATION positions
+void launch_encode_scatter(const DevConsts *dc, u32 N, u32 M, const int64_t *slots, u32 B, const u32 *inv_pos, u64 *u,
+                           u32 npt, hipStream_t st);
+// coefficients mod t [npt][N] -> centred lift into every q_i: out[npt][L][N]
+void launch_encode_lift(const DevConsts *dc, u32 N, u32 L, u32 M, const u64 *u, u64 *out, u32 npt, hipStream_t st);
+
+}  // namespace piehip

@@ -1,0 +1,767 @@
+// piehip.cpp -- C ABI (include/piehip.h) over the gfx950 kernels: device memory, streams, the
+// launch schedule of BatchedFHEHIPPIE::run() (reference BatchedFHEHIPPIE.cpp:88-129) and the
+// kernel-level entry points used by the parity tests.
+#include "../../include/piehip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "params.hpp"
+
+using namespace piehip;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(PIEHIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+#define NEED(h)                                                 \
+    do {                                                        \
+        if (!(h)) return fail(PIEHIP_EINVAL, "null handle");    \
+    } while (0)
+
+namespace {
+
+struct ProfRec {
+    hipEvent_t a, b;
+    int k;
+    double bytes;
+};
+
+// scratch of one batched EvalMult(ct,ct) over nb ciphertext pairs
+struct MulWs {
+    u32 nb = 0;
+    u64 *eqp = nullptr;  // [nb][4][M][N]
+    u64 *dqp = nullptr;  // [nb][3][M][N]
+    u64 *d01 = nullptr;  // [nb][2][L][N]
+    u64 *d2c = nullptr;  // [nb][L][N]
+    u64 *dig = nullptr;  // [nb][L][L][N]
+};
+
+}  // namespace
+
+struct piehip_ctx {
+    HostParams hp;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevConsts *d_dc = nullptr;
+    u64 *d_tables = nullptr;  // [(M+1)][4][N]
+    u32 *d_inv_pos = nullptr; // EVALUATION position -> slot
+    NttPlan plan;
+    // keys / database / inputs
+    u64 *d_evk = nullptr;
+    u32 K = 0, b = 0, E = 0;
+    u64 *d_db = nullptr, *d_masks = nullptr;
+    u64 *d_idx_own = nullptr, *d_minus_own = nullptr;
+    const u64 *d_idx = nullptr, *d_minus = nullptr;
+    // run() workspace
+    u64 *d_acc = nullptr;   // [b][K][2][L][N]
+    u64 *d_prod = nullptr;  // [b][2][L][N]  (K > 2 only)
+    u64 *d_out = nullptr;   // [b][2][L][N]
+    MulWs ws;
+    // profiling
+    bool profiling = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t pool_used = 0;
+
+    size_t LN() const { return (size_t)hp.L * hp.N; }
+};
+
+static const char *KNAMES[PIEHIP_NKERNELS] = {"stage_a_mac", "ntt_fwd", "ntt_inv",  "expand",   "tensor",    "scale_round",
+                                              "digits",      "relin",   "mask_mul", "encode",   "automorph", "other"};
+
+// ---- profiling helpers -------------------------------------------------------------------------
+static hipEvent_t prof_event(piehip_ctx *h)
+{
+    if (h->pool_used == h->pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        h->pool.push_back(e);
+    }
+    return h->pool[h->pool_used++];
+}
+struct ProfScope {
+    piehip_ctx *h;
+    ProfRec r;
+    bool on;
+    ProfScope(piehip_ctx *h_, int k, double bytes) : h(h_), on(h_->profiling)
+    {
+        if (!on) return;
+        r.k = k;
+        r.bytes = bytes;
+        r.a = prof_event(h);
+        r.b = prof_event(h);
+        if (!r.a || !r.b) {
+            on = false;
+            return;
+        }
+        (void)hipEventRecord(r.a, h->stream);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(r.b, h->stream);
+        h->recs.push_back(r);
+    }
+};
+
+static int dev_alloc(u64 **p, size_t words)
+{
+    *p = nullptr;
+    if (!words) return PIEHIP_OK;
+    hipError_t e = hipMalloc((void **)p, words * sizeof(u64));
+    if (e != hipSuccess) return fail(PIEHIP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return PIEHIP_OK;
+}
+static void dev_free(u64 **p)
+{
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+}
+
+static int ws_alloc(piehip_ctx *h, MulWs &w, u32 nb)
+{
+    const size_t N = h->hp.N, L = h->hp.L, M = h->hp.M;
+    w.nb = nb;
+    int rc;
+    if ((rc = dev_alloc(&w.eqp, (size_t)nb * 4 * M * N))) return rc;
+    if ((rc = dev_alloc(&w.dqp, (size_t)nb * 3 * M * N))) return rc;
+    if ((rc = dev_alloc(&w.d01, (size_t)nb * 2 * L * N))) return rc;
+    if ((rc = dev_alloc(&w.d2c, (size_t)nb * L * N))) return rc;
+    if ((rc = dev_alloc(&w.dig, (size_t)nb * L * L * N))) return rc;
+    return PIEHIP_OK;
+}
+static void ws_free(MulWs &w)
+{
+    dev_free(&w.eqp);
+    dev_free(&w.dqp);
+    dev_free(&w.d01);
+    dev_free(&w.d2c);
+    dev_free(&w.dig);
+    w.nb = 0;
+}
+
+// ---- schedule pieces ----------------------------------------------------------------------------
+static void ntt(piehip_ctx *h, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inv)
+{
+    ProfScope ps(h, inv ? PIEHIP_K_NTT_INV : PIEHIP_K_NTT_FWD, 16.0 * h->hp.N * nlimbs);
+    launch_ntt(h->plan, data, nlimbs, mod_base, mod_count, inv, h->stream);
+}
+
+// BV key switch of the COEFFICIENT-format polynomials at w.d2c with `key`, added to the EVALUATION
+// ciphertexts at w.d01, optionally multiplied by mask plaintexts: out[nb][2][L][N]
+static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, const u64 *mask, u64 *out)
+{
+    const u32 N = h->hp.N, L = h->hp.L;
+    const size_t LN = h->LN();
+    const double W = 8.0 * N;
+    {
+        ProfScope ps(h, PIEHIP_K_DIGITS, W * nb * (L + (double)L * L));
+        launch_digits(h->d_dc, N, L, w.d2c, LN, nb, w.dig, h->stream);
+    }
+    ntt(h, w.dig, nb * L * L, 0, L, false);
+    {
+        ProfScope ps(h, PIEHIP_K_RELIN, W * (nb * ((double)L * L + 2 * L + 2 * L + (mask ? L : 0)) + 2.0 * L * L));
+        launch_relin_mac(h->d_dc, N, L, w.d01, 2 * LN, w.dig, key, mask, out, nb, h->stream);
+    }
+}
+
+// One batched EvalMult(ct,ct) (BatchedFHEHIPPIE.cpp:123): operands in COEFFICIENT format,
+// X polynomial (o,c) at x + o*sx + c*LN, Y likewise.  relin: out[nb][2][L][N] (times mask if given);
+// otherwise out[nb][3][L][N] holds the EVALUATION-format tensor result.
+static void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const u64 *y, size_t sy, u32 nb, bool relin,
+                        const u64 *mask, u64 *out)
+{
+    const u32 N = h->hp.N, L = h->hp.L, M = h->hp.M;
+    const size_t LN = h->LN();
+    const double W = 8.0 * N;
+    {
+        ProfScope ps(h, PIEHIP_K_EXPAND, W * nb * (4.0 * L + 4.0 * M));
+        launch_expand_q_to_qp(h->d_dc, N, L, x, sx, LN, nb, w.eqp, 4, 0, h->stream);
+        launch_scale_pq_expand(h->d_dc, N, L, y, sy, LN, nb, w.eqp, 4, 2, h->stream);
+    }
+    ntt(h, w.eqp, nb * 4 * M, 0, M, false);
+    {
+        ProfScope ps(h, PIEHIP_K_TENSOR, W * nb * 7.0 * M);
+        launch_tensor(h->d_dc, N, M, w.eqp, w.dqp, nb, h->stream);
+    }
+    ntt(h, w.dqp, nb * 3 * M, 0, M, true);
+    if (relin) {
+        {
+            ProfScope ps(h, PIEHIP_K_SCALE, W * nb * (3.0 * M + 3.0 * L));
+            launch_scale_round(h->d_dc, N, L, w.dqp, nb, w.d01, 2 * LN, w.d2c, LN, h->stream);
+        }
+        ntt(h, w.d01, nb * 2 * L, 0, L, false);
+        enqueue_keyswitch(h, w, nb, h->d_evk, mask, out);
+    } else {
+        {
+            ProfScope ps(h, PIEHIP_K_SCALE, W * nb * (3.0 * M + 3.0 * L));
+            launch_scale_round(h->d_dc, N, L, w.dqp, nb, out, 3 * LN, out + 2 * LN, 3 * LN, h->stream);
+        }
+        ntt(h, out, nb * 3 * L, 0, L, false);
+    }
+}
+
+// =================================================================================================
+extern "C" {
+
+int piehip_version(void) { return 100; }
+const char *piehip_last_error(void) { return g_err.c_str(); }
+const char *piehip_kernel_name(int k) { return (k >= 0 && k < PIEHIP_NKERNELS) ? KNAMES[k] : "?"; }
+
+int piehip_default_moduli(uint32_t N, uint32_t L, uint64_t *q, uint64_t *p)
+{
+    if (!q || !p || L < 1 || L > MAX_L || N < 8 || (N & (N - 1))) return fail(PIEHIP_EINVAL, "bad N/L");
+    std::vector<u64> ch(2 * L + 1);
+    if (!prime_chain(N, 1ULL << 60, 2 * L + 1, ch.data())) return fail(PIEHIP_EINVAL, "prime chain exhausted");
+    memcpy(q, ch.data(), sizeof(u64) * L);
+    memcpy(p, ch.data() + L, sizeof(u64) * (L + 1));
+    return PIEHIP_OK;
+}
+
+int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const uint64_t *q, const uint64_t *p, int device,
+                  void *stream)
+{
+    if (!out) return fail(PIEHIP_EINVAL, "null out");
+    *out = nullptr;
+    piehip_ctx *h = new piehip_ctx();
+    std::string err = h->hp.init(N, L, t, q, p);
+    if (!err.empty()) {
+        delete h;
+        return fail(PIEHIP_EINVAL, err);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        delete h;
+        return fail(PIEHIP_EHIP, "no HIP device visible: libpiehip has no CPU fallback");
+    }
+    h->device = device;
+#define CHK_(expr)                                                                          \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e_);             \
+            piehip_destroy(h);                                                              \
+            return fail(PIEHIP_EHIP, m_);                                                   \
+        }                                                                                   \
+    } while (0)
+    CHK_(hipSetDevice(device));
+    if (stream) {
+        h->stream = (hipStream_t)stream;
+    } else {
+        CHK_(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    const u32 M = h->hp.M;
+    CHK_(hipMalloc((void **)&h->d_dc, sizeof(DevConsts)));
+    CHK_(hipMemcpy(h->d_dc, &h->hp.dc, sizeof(DevConsts), hipMemcpyHostToDevice));
+    CHK_(hipMalloc((void **)&h->d_tables, sizeof(u64) * (size_t)(M + 1) * 4 * N));
+    for (u32 a = 0; a <= M; a++) {
+        u64 *base = h->d_tables + (size_t)a * 4 * N;
+        CHK_(hipMemcpy(base, h->hp.tw[a].data(), sizeof(u64) * N, hipMemcpyHostToDevice));
+        CHK_(hipMemcpy(base + N, h->hp.tw_sh[a].data(), sizeof(u64) * N, hipMemcpyHostToDevice));
+        CHK_(hipMemcpy(base + 2 * (size_t)N, h->hp.itw[a].data(), sizeof(u64) * N, hipMemcpyHostToDevice));
+        CHK_(hipMemcpy(base + 3 * (size_t)N, h->hp.itw_sh[a].data(), sizeof(u64) * N, hipMemcpyHostToDevice));
+    }
+    {
+        std::vector<u32> inv(N, 0xFFFFFFFFu);
+        for (u32 s = 0; s < N; s++) inv[h->hp.slot_pos[s]] = s;
+        CHK_(hipMalloc((void **)&h->d_inv_pos, sizeof(u32) * N));
+        CHK_(hipMemcpy(h->d_inv_pos, inv.data(), sizeof(u32) * N, hipMemcpyHostToDevice));
+    }
+#undef CHK_
+    h->plan.tables = h->d_tables;
+    h->plan.dc = h->d_dc;
+    h->plan.N = N;
+    h->plan.logN = h->hp.logN;
+    *out = h;
+    return PIEHIP_OK;
+}
+
+int piehip_destroy(piehip_handle h)
+{
+    if (!h) return PIEHIP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipEvent_t e : h->pool) (void)hipEventDestroy(e);
+    dev_free(&h->d_evk);
+    dev_free(&h->d_db);
+    dev_free(&h->d_masks);
+    dev_free(&h->d_idx_own);
+    dev_free(&h->d_minus_own);
+    dev_free(&h->d_acc);
+    dev_free(&h->d_prod);
+    dev_free(&h->d_out);
+    ws_free(h->ws);
+    if (h->d_dc) (void)hipFree(h->d_dc);
+    if (h->d_tables) (void)hipFree(h->d_tables);
+    if (h->d_inv_pos) (void)hipFree(h->d_inv_pos);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PIEHIP_OK;
+}
+
+int piehip_get_moduli(piehip_handle h, uint64_t *out)
+{
+    NEED(h);
+    memcpy(out, h->hp.moduli.data(), sizeof(u64) * (h->hp.M + 1));
+    return PIEHIP_OK;
+}
+int piehip_get_root(piehip_handle h, uint32_t mi, uint64_t *psi)
+{
+    NEED(h);
+    if (mi > h->hp.M) return fail(PIEHIP_EINVAL, "mod_index out of range");
+    *psi = h->hp.psi[mi];
+    return PIEHIP_OK;
+}
+int piehip_get_twiddles(piehip_handle h, uint32_t mi, uint64_t *fwd, uint64_t *inv)
+{
+    NEED(h);
+    if (mi > h->hp.M) return fail(PIEHIP_EINVAL, "mod_index out of range");
+    if (fwd) memcpy(fwd, h->hp.tw[mi].data(), sizeof(u64) * h->hp.N);
+    if (inv) memcpy(inv, h->hp.itw[mi].data(), sizeof(u64) * h->hp.N);
+    return PIEHIP_OK;
+}
+int piehip_get_slot_positions(piehip_handle h, uint32_t *pos)
+{
+    NEED(h);
+    memcpy(pos, h->hp.slot_pos.data(), sizeof(u32) * h->hp.N);
+    return PIEHIP_OK;
+}
+
+int piehip_load_relin_key(piehip_handle h, const uint64_t *evk)
+{
+    NEED(h);
+    if (!evk) return fail(PIEHIP_EINVAL, "null evk");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t words = (size_t)h->hp.L * 2 * h->LN();
+    if (!h->d_evk) {
+        int rc = dev_alloc(&h->d_evk, words);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpy(h->d_evk, evk, words * sizeof(u64), hipMemcpyHostToDevice));
+    return PIEHIP_OK;
+}
+
+static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E)
+{
+    if (K < 2) return fail(PIEHIP_EINVAL, "Cuckoo Table needs more than one hash function!");  // CuckooHashTable.cpp:39-42
+    if (b < 1 || E < 1) return fail(PIEHIP_EINVAL, "Bin size needs to be at least of size one!");
+    const size_t LN = h->LN();
+    dev_free(&h->d_db);
+    dev_free(&h->d_masks);
+    dev_free(&h->d_acc);
+    dev_free(&h->d_prod);
+    dev_free(&h->d_out);
+    ws_free(h->ws);
+    h->K = h->b = h->E = 0;
+    int rc;
+    if ((rc = dev_alloc(&h->d_db, (size_t)K * b * E * LN))) return rc;
+    if ((rc = dev_alloc(&h->d_masks, (size_t)b * LN))) return rc;
+    if ((rc = dev_alloc(&h->d_acc, (size_t)b * K * 2 * LN))) return rc;
+    if ((rc = dev_alloc(&h->d_out, (size_t)b * 2 * LN))) return rc;
+    if (K > 2 && (rc = dev_alloc(&h->d_prod, (size_t)b * 2 * LN))) return rc;
+    if ((rc = ws_alloc(h, h->ws, b))) return rc;
+    h->K = K;
+    h->b = b;
+    h->E = E;
+    // inputs depend on K,E: drop stale copies
+    dev_free(&h->d_idx_own);
+    h->d_idx = nullptr;
+    return PIEHIP_OK;
+}
+
+int piehip_load_db(piehip_handle h, uint32_t K, uint32_t b, uint32_t E, const uint64_t *pts, const uint64_t *masks)
+{
+    NEED(h);
+    if (!pts || !masks) return fail(PIEHIP_EINVAL, "null database");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = alloc_run_buffers(h, K, b, E);
+    if (rc) return rc;
+    const size_t LN = h->LN();
+    HIPCHK(hipMemcpy(h->d_db, pts, sizeof(u64) * (size_t)K * b * E * LN, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_masks, masks, sizeof(u64) * (size_t)b * LN, hipMemcpyHostToDevice));
+    return PIEHIP_OK;
+}
+
+// device-side MakePackedPlaintext of npt slot vectors (already on the device) into out[npt][L][N]
+static int encode_on_device(piehip_ctx *h, const int64_t *d_slots, u32 npt, u32 B, u64 *d_out)
+{
+    const u32 N = h->hp.N, L = h->hp.L, M = h->hp.M;
+    // chunk so the mod-t scratch stays small
+    const u32 chunk = 256;
+    u64 *d_u = nullptr;
+    int rc = dev_alloc(&d_u, (size_t)(npt < chunk ? npt : chunk) * N);
+    if (rc) return rc;
+    for (u32 s = 0; s < npt; s += chunk) {
+        const u32 c = npt - s < chunk ? npt - s : chunk;
+        ProfScope ps(h, PIEHIP_K_ENCODE, 8.0 * c * ((double)B + 2.0 * N + (double)L * N));
+        launch_encode_scatter(h->d_dc, N, M, d_slots + (size_t)s * B, B, h->d_inv_pos, d_u, c, h->stream);
+        launch_ntt(h->plan, d_u, c, M, 1, true, h->stream);
+        launch_encode_lift(h->d_dc, N, L, M, d_u, d_out + (size_t)s * L * N, c, h->stream);
+        launch_ntt(h->plan, d_out + (size_t)s * L * N, c * L, 0, L, false, h->stream);
+    }
+    hipError_t e = hipStreamSynchronize(h->stream);
+    dev_free(&d_u);
+    if (e != hipSuccess) return fail(PIEHIP_EHIP, std::string("encode: ") + hipGetErrorString(e));
+    return PIEHIP_OK;
+}
+
+int piehip_load_db_slots(piehip_handle h, uint32_t K, uint32_t b, uint32_t E, uint32_t B, const int64_t *slots,
+                         const int64_t *mask_slots)
+{
+    NEED(h);
+    if (!slots || !mask_slots) return fail(PIEHIP_EINVAL, "null database");
+    if (B > h->hp.N) return fail(PIEHIP_EINVAL, "batch size exceeds the ring dimension");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = alloc_run_buffers(h, K, b, E);
+    if (rc) return rc;
+    const size_t npt = (size_t)K * b * E;
+    int64_t *d_s = nullptr;
+    HIPCHK(hipMalloc((void **)&d_s, sizeof(int64_t) * (npt > b ? npt : b) * B));
+    hipError_t e = hipMemcpy(d_s, slots, sizeof(int64_t) * npt * B, hipMemcpyHostToDevice);
+    if (e == hipSuccess) rc = encode_on_device(h, d_s, (u32)npt, B, h->d_db);
+    if (e == hipSuccess && rc == PIEHIP_OK) e = hipMemcpy(d_s, mask_slots, sizeof(int64_t) * (size_t)b * B, hipMemcpyHostToDevice);
+    if (e == hipSuccess && rc == PIEHIP_OK) rc = encode_on_device(h, d_s, b, B, h->d_masks);
+    (void)hipFree(d_s);
+    if (e != hipSuccess) return fail(PIEHIP_EHIP, std::string("load_db_slots: ") + hipGetErrorString(e));
+    return rc;
+}
+
+int piehip_set_index(piehip_handle h, const uint64_t *idx)
+{
+    NEED(h);
+    if (!idx) return fail(PIEHIP_EINVAL, "null index matrix");
+    if (!h->K) return fail(PIEHIP_ESTATE, "load the database before the index matrix");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t words = (size_t)h->K * h->E * 2 * h->LN();
+    if (!h->d_idx_own) {
+        int rc = dev_alloc(&h->d_idx_own, words);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(h->d_idx_own, idx, words * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->d_idx = h->d_idx_own;
+    return PIEHIP_OK;
+}
+int piehip_set_minus(piehip_handle h, const uint64_t *minus)
+{
+    NEED(h);
+    if (!minus) return fail(PIEHIP_EINVAL, "null minus element");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t words = 2 * h->LN();
+    if (!h->d_minus_own) {
+        int rc = dev_alloc(&h->d_minus_own, words);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(h->d_minus_own, minus, words * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->d_minus = h->d_minus_own;
+    return PIEHIP_OK;
+}
+int piehip_set_index_device(piehip_handle h, const void *d_idx)
+{
+    NEED(h);
+    if (!d_idx) return fail(PIEHIP_EINVAL, "null index matrix");
+    h->d_idx = (const u64 *)d_idx;
+    return PIEHIP_OK;
+}
+int piehip_set_minus_device(piehip_handle h, const void *d_minus)
+{
+    NEED(h);
+    if (!d_minus) return fail(PIEHIP_EINVAL, "null minus element");
+    h->d_minus = (const u64 *)d_minus;
+    return PIEHIP_OK;
+}
+
+int piehip_run(piehip_handle h)
+{
+    NEED(h);
+    if (!h->K || !h->d_db) return fail(PIEHIP_ESTATE, "run: database not loaded");
+    if (!h->d_evk) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
+    if (!h->d_idx || !h->d_minus) return fail(PIEHIP_ESTATE, "run: setIndex / setMinusCompareElement not called");
+    HIPCHK(hipSetDevice(h->device));
+    const u32 N = h->hp.N, L = h->hp.L, K = h->K, b = h->b, E = h->E;
+    const size_t LN = h->LN();
+    const double W = 8.0 * N;
+    h->recs.clear();
+    h->pool_used = 0;
+    {   // stage A: all inner products of all bin layers in one launch (BatchedFHEHIPPIE.cpp:101-116)
+        ProfScope ps(h, PIEHIP_K_STAGE_A, W * ((double)b * K * E * L + (double)K * E * 2 * L + 2.0 * L + (double)b * K * 2 * L));
+        launch_stage_a(h->d_dc, N, L, K, b, E, h->d_idx, h->d_minus, h->d_db, h->d_acc, h->stream);
+    }
+    // every accumulator enters a ct x ct product exactly once: switch them all to COEFFICIENT format
+    ntt(h, h->d_acc, b * K * 2 * L, 0, L, true);
+    // product chain over the inner hash functions (BatchedFHEHIPPIE.cpp:117-124); the mask multiply
+    // (:126) is fused into the last key switch
+    const u64 *x = h->d_acc;
+    size_t sx = (size_t)K * 2 * LN;
+    for (u32 hf = 1; hf < K; hf++) {
+        const bool last = hf + 1 == K;
+        u64 *dst = last ? h->d_out : h->d_prod;
+        enqueue_mul(h, h->ws, x, sx, h->d_acc + (size_t)hf * 2 * LN, (size_t)K * 2 * LN, b, true, last ? h->d_masks : nullptr, dst);
+        if (!last) {
+            ntt(h, h->d_prod, b * 2 * L, 0, L, true);
+            x = h->d_prod;
+            sx = 2 * LN;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return PIEHIP_OK;
+}
+
+int piehip_sync(piehip_handle h)
+{
+    NEED(h);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PIEHIP_OK;
+}
+
+int piehip_get_results(piehip_handle h, uint64_t *out)
+{
+    NEED(h);
+    if (!out) return fail(PIEHIP_EINVAL, "null out");
+    if (!h->d_out) return fail(PIEHIP_ESTATE, "no results");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(out, h->d_out, sizeof(u64) * (size_t)h->b * 2 * h->LN(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PIEHIP_OK;
+}
+int piehip_results_device(piehip_handle h, void **d_out)
+{
+    NEED(h);
+    if (!h->d_out) return fail(PIEHIP_ESTATE, "no results");
+    *d_out = h->d_out;
+    return PIEHIP_OK;
+}
+
+// ---- kernel-level entry points (tests) -------------------------------------------------------------
+namespace {
+struct Tmp {  // RAII device scratch for the synchronous test entry points
+    std::vector<u64 *> ptrs;
+    ~Tmp()
+    {
+        for (u64 *p : ptrs) (void)hipFree(p);
+    }
+    u64 *get(size_t words)
+    {
+        u64 *p = nullptr;
+        if (hipMalloc((void **)&p, (words ? words : 1) * sizeof(u64)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return p;
+    }
+};
+}  // namespace
+#define TMPGET(var, words)                                          \
+    u64 *var = tmp.get(words);                                      \
+    if (!var) return fail(PIEHIP_ENOMEM, "hipMalloc failed (scratch)")
+
+int piehip_ntt(piehip_handle h, uint64_t *limbs, uint32_t nlimbs, uint32_t mod_base, uint32_t mod_count, int inverse)
+{
+    NEED(h);
+    if (!limbs || !mod_count || mod_base + mod_count > h->hp.M + 1) return fail(PIEHIP_EINVAL, "bad modulus range");
+    HIPCHK(hipSetDevice(h->device));
+    Tmp tmp;
+    const size_t words = (size_t)nlimbs * h->hp.N;
+    TMPGET(d, words);
+    HIPCHK(hipMemcpy(d, limbs, words * sizeof(u64), hipMemcpyHostToDevice));
+    ntt(h, d, nlimbs, mod_base, mod_count, inverse != 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(limbs, d, words * sizeof(u64), hipMemcpyDeviceToHost));
+    return PIEHIP_OK;
+}
+
+static int ew_common(piehip_handle h, const uint64_t *x, const uint64_t *y, uint64_t *out, bool mul)
+{
+    NEED(h);
+    if (!x || !y || !out) return fail(PIEHIP_EINVAL, "null operand");
+    HIPCHK(hipSetDevice(h->device));
+    Tmp tmp;
+    const size_t LN = h->LN();
+    TMPGET(dx, 2 * LN);
+    TMPGET(dy, 2 * LN);
+    TMPGET(dz, 2 * LN);
+    HIPCHK(hipMemcpy(dx, x, 2 * LN * sizeof(u64), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dy, y, (mul ? 1 : 2) * LN * sizeof(u64), hipMemcpyHostToDevice));
+    if (mul)
+        launch_ct_mul_plain(h->d_dc, h->hp.N, h->hp.L, dx, dy, 0, dz, 1, h->stream);
+    else
+        launch_ct_add(h->d_dc, h->hp.N, h->hp.L, dx, dy, dz, 1, h->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, dz, 2 * LN * sizeof(u64), hipMemcpyDeviceToHost));
+    return PIEHIP_OK;
+}
+int piehip_eval_add(piehip_handle h, const uint64_t *x, const uint64_t *y, uint64_t *out) { return ew_common(h, x, y, out, false); }
+int piehip_eval_mult_plain(piehip_handle h, const uint64_t *x, const uint64_t *pt, uint64_t *out)
+{
+    return ew_common(h, x, pt, out, true);
+}
+
+int piehip_eval_mult(piehip_handle h, const uint64_t *x, const uint64_t *y, uint32_t nct, int relin, uint64_t *out)
+{
+    NEED(h);
+    if (!x || !y || !out || !nct) return fail(PIEHIP_EINVAL, "null operand");
+    if (relin && !h->d_evk) return fail(PIEHIP_ESTATE, "relinearisation key not loaded");
+    HIPCHK(hipSetDevice(h->device));
+    Tmp tmp;
+    const size_t LN = h->LN();
+    const u32 L = h->hp.L;
+    TMPGET(dxy, (size_t)nct * 4 * LN);  // [nct][x,y][2][L][N]
+    TMPGET(dout, (size_t)nct * 3 * LN);
+    for (u32 i = 0; i < nct; i++) {
+        HIPCHK(hipMemcpy(dxy + (size_t)i * 4 * LN, x + (size_t)i * 2 * LN, 2 * LN * sizeof(u64), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dxy + (size_t)i * 4 * LN + 2 * LN, y + (size_t)i * 2 * LN, 2 * LN * sizeof(u64), hipMemcpyHostToDevice));
+    }
+    MulWs w;
+    int rc = ws_alloc(h, w, nct);
+    if (rc) {
+        ws_free(w);
+        return rc;
+    }
+    ntt(h, dxy, nct * 4 * L, 0, L, true);
+    enqueue_mul(h, w, dxy, 4 * LN, dxy + 2 * LN, 4 * LN, nct, relin != 0, nullptr, dout);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    ws_free(w);
+    if (e != hipSuccess) return fail(PIEHIP_EHIP, std::string("eval_mult: ") + hipGetErrorString(e));
+    HIPCHK(hipMemcpy(out, dout, (size_t)nct * (relin ? 2 : 3) * LN * sizeof(u64), hipMemcpyDeviceToHost));
+    return PIEHIP_OK;
+}
+
+int piehip_eval_automorph(piehip_handle h, const uint64_t *x, uint32_t g, const uint64_t *rk, uint64_t *out)
+{
+    NEED(h);
+    if (!x || !rk || !out) return fail(PIEHIP_EINVAL, "null operand");
+    if (!(g & 1) || g >= 2 * h->hp.N) return fail(PIEHIP_EINVAL, "automorphism index must be odd and < 2N");
+    HIPCHK(hipSetDevice(h->device));
+    Tmp tmp;
+    const size_t LN = h->LN();
+    const u32 N = h->hp.N, L = h->hp.L;
+    TMPGET(dx, 2 * LN);
+    TMPGET(dk, (size_t)L * 2 * LN);
+    TMPGET(dperm, 2 * LN);
+    TMPGET(dout, 2 * LN);
+    TMPGET(dmapw, (N + 1) / 2 + 1);
+    u32 *dmap = (u32 *)dmapw;
+    std::vector<u32> map = h->hp.automorph_map(g);
+    HIPCHK(hipMemcpy(dx, x, 2 * LN * sizeof(u64), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dk, rk, (size_t)L * 2 * LN * sizeof(u64), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dmap, map.data(), sizeof(u32) * N, hipMemcpyHostToDevice));
+    MulWs w;
+    int rc = ws_alloc(h, w, 1);
+    if (rc) {
+        ws_free(w);
+        return rc;
+    }
+    {
+        ProfScope ps(h, PIEHIP_K_AUTOMORPH, 16.0 * N * 2 * L);
+        launch_permute(N, dx, dmap, dperm, 2 * L, h->stream);
+    }
+    // (sigma(c0), 0) stays in EVALUATION format; sigma(c1) goes through the key switch
+    (void)hipMemcpyAsync(w.d01, dperm, LN * sizeof(u64), hipMemcpyDeviceToDevice, h->stream);
+    (void)hipMemsetAsync(w.d01 + LN, 0, LN * sizeof(u64), h->stream);
+    (void)hipMemcpyAsync(w.d2c, dperm + LN, LN * sizeof(u64), hipMemcpyDeviceToDevice, h->stream);
+    ntt(h, w.d2c, L, 0, L, true);
+    enqueue_keyswitch(h, w, 1, dk, nullptr, dout);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    ws_free(w);
+    if (e != hipSuccess) return fail(PIEHIP_EHIP, std::string("eval_automorph: ") + hipGetErrorString(e));
+    HIPCHK(hipMemcpy(out, dout, 2 * LN * sizeof(u64), hipMemcpyDeviceToHost));
+    return PIEHIP_OK;
+}
+
+int piehip_encode(piehip_handle h, const int64_t *slots, uint32_t npt, uint32_t B, uint64_t *out)
+{
+    NEED(h);
+    if (!slots || !out || !npt) return fail(PIEHIP_EINVAL, "null operand");
+    if (B > h->hp.N) return fail(PIEHIP_EINVAL, "batch size exceeds the ring dimension");
+    const u64 t = h->hp.t;
+    for (size_t i = 0; i < (size_t)npt * B; i++) {
+        const int64_t v = slots[i];
+        if ((u64)(v < 0 ? -v : v) >= t) return fail(PIEHIP_EINVAL, "slot value out of range for the plaintext modulus");
+    }
+    HIPCHK(hipSetDevice(h->device));
+    Tmp tmp;
+    TMPGET(dsw, (size_t)npt * B);
+    TMPGET(dout, (size_t)npt * h->LN());
+    HIPCHK(hipMemcpy(dsw, slots, sizeof(int64_t) * (size_t)npt * B, hipMemcpyHostToDevice));
+    int rc = encode_on_device(h, (const int64_t *)dsw, npt, B, dout);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out, dout, sizeof(u64) * (size_t)npt * h->LN(), hipMemcpyDeviceToHost));
+    return PIEHIP_OK;
+}
+
+int piehip_base_convert(piehip_handle h, int which, const uint64_t *in, uint32_t npoly, uint64_t *out)
+{
+    NEED(h);
+    if (!in || !out || !npoly || which < 0 || which > 2) return fail(PIEHIP_EINVAL, "bad argument");
+    if (which == 2 && npoly % 3) return fail(PIEHIP_EINVAL, "scale-and-round takes polynomials in triples");
+    if (which != 2 && npoly % 2) return fail(PIEHIP_EINVAL, "extension takes polynomials in pairs");
+    HIPCHK(hipSetDevice(h->device));
+    Tmp tmp;
+    const u32 N = h->hp.N, L = h->hp.L, M = h->hp.M;
+    const size_t LN = h->LN(), MN = (size_t)M * N;
+    const size_t win = (size_t)npoly * (which == 2 ? MN : LN), wout = (size_t)npoly * (which == 2 ? LN : MN);
+    TMPGET(din, win);
+    TMPGET(dout, wout);
+    HIPCHK(hipMemcpy(din, in, win * sizeof(u64), hipMemcpyHostToDevice));
+    if (which == 0)
+        launch_expand_q_to_qp(h->d_dc, N, L, din, 2 * LN, LN, npoly / 2, dout, 2, 0, h->stream);
+    else if (which == 1)
+        launch_scale_pq_expand(h->d_dc, N, L, din, 2 * LN, LN, npoly / 2, dout, 2, 0, h->stream);
+    else
+        launch_scale_round(h->d_dc, N, L, din, npoly / 3, dout, 3 * LN, dout + 2 * LN, 3 * LN, h->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, dout, wout * sizeof(u64), hipMemcpyDeviceToHost));
+    return PIEHIP_OK;
+}
+
+int piehip_set_profiling(piehip_handle h, int on)
+{
+    NEED(h);
+    h->profiling = on != 0;
+    h->recs.clear();
+    h->pool_used = 0;
+    return PIEHIP_OK;
+}
+
+int piehip_profile_read(piehip_handle h, uint32_t *launches, double *ms, double *alg_bytes)
+{
+    NEED(h);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < PIEHIP_NKERNELS; k++) {
+        if (launches) launches[k] = 0;
+        if (ms) ms[k] = 0;
+        if (alg_bytes) alg_bytes[k] = 0;
+    }
+    for (const ProfRec &r : h->recs) {
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
+        if (launches) launches[r.k]++;
+        if (ms) ms[r.k] += t;
+        if (alg_bytes) alg_bytes[r.k] += r.bytes;
+    }
+    return PIEHIP_OK;
+}
+
+}  // extern "C"

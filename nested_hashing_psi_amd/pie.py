@@ -1,0 +1,228 @@
+"""Host-side mirror of the reference operator interface, over the C ABI.
+
+  PieContext        <-> lbcrypto::CryptoContext<DCRTPoly> as the server holds it
+                        (reference src/Server/FHE/BatchedFHEPSIServer.hpp:21, set at .cpp:21-54)
+  BatchedFHEHIPPIE  <-> class BatchedFHEHIPPIE, reference
+                        src/Common/Crypto/PrivateIndexedEqualityCheck/BatchedFHEHIPPIE.hpp:18-49:
+                        same method names (setIndex, setMinusCompareElement, run, getResultList),
+                        same argument meaning, same error behaviour (ValueError where the
+                        reference throws std::invalid_argument, RuntimeError for runtime_error).
+Ciphertexts / plaintexts are numpy uint64 limb arrays in EVALUATION format, the layout of OpenFHE's
+DCRTPoly towers.  Everything executes in libpiehip.so on the GPU; nothing here computes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import NKERNELS, f64p, i64p, lib, u32p, u64p
+
+EINVAL, ESTATE, EHIP, ENOMEM = -1, -2, -3, -4
+
+
+def _check(rc):
+    if rc == 0:
+        return
+    msg = lib().piehip_last_error().decode()
+    if rc == EINVAL:
+        raise ValueError(msg)          # reference: std::invalid_argument
+    if rc == ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)            # reference: std::runtime_error / OpenFHE exceptions
+
+
+def _u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(u64p)
+
+
+def default_moduli(N, L):
+    q = np.zeros(L, dtype=np.uint64)
+    p = np.zeros(L + 1, dtype=np.uint64)
+    _check(lib().piehip_default_moduli(N, L, q.ctypes.data_as(u64p), p.ctypes.data_as(u64p)))
+    return q, p
+
+
+class PieContext:
+    """BFV-RNS evaluation context on one GPU (ring dimension N, L primes, plaintext modulus t)."""
+
+    def __init__(self, N, L, t, q=None, p=None, device=0, stream=None):
+        self.N, self.L, self.t, self.M = N, L, int(t), 2 * L + 1
+        self._h = C.c_void_p()
+        qa = pa = None
+        if q is not None:
+            qa_arr, qa = _u64(q)
+            pa_arr, pa = _u64(p)
+        _check(lib().piehip_create(C.byref(self._h), N, L, int(t), qa, pa, device, stream))
+        m = np.zeros(self.M + 1, dtype=np.uint64)
+        _check(lib().piehip_get_moduli(self._h, m.ctypes.data_as(u64p)))
+        self.moduli = m
+        self.q, self.p = m[:L].copy(), m[L:self.M].copy()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().piehip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    # -- tables (for cross-checks)
+    def psi(self, mi):
+        v = C.c_uint64()
+        _check(lib().piehip_get_root(self._h, mi, C.byref(v)))
+        return int(v.value)
+
+    def twiddles(self, mi):
+        f = np.zeros(self.N, dtype=np.uint64)
+        i = np.zeros(self.N, dtype=np.uint64)
+        _check(lib().piehip_get_twiddles(self._h, mi, f.ctypes.data_as(u64p), i.ctypes.data_as(u64p)))
+        return f, i
+
+    def slot_positions(self):
+        pos = np.zeros(self.N, dtype=np.uint32)
+        _check(lib().piehip_get_slot_positions(self._h, pos.ctypes.data_as(u32p)))
+        return pos
+
+    # -- the OpenFHE primitives under run()
+    def ntt(self, limbs, mod_base=0, mod_count=None, inverse=False):
+        a = np.array(limbs, dtype=np.uint64, order="C")
+        flat = a.reshape(-1, self.N)
+        if mod_count is None:
+            mod_count = self.L
+        _check(lib().piehip_ntt(self._h, flat.ctypes.data_as(u64p), flat.shape[0], mod_base, mod_count, int(inverse)))
+        return a
+
+    def EvalAdd(self, x, y):
+        xa, xp = _u64(x)
+        ya, yp = _u64(y)
+        out = np.zeros_like(xa)
+        _check(lib().piehip_eval_add(self._h, xp, yp, out.ctypes.data_as(u64p)))
+        return out
+
+    def EvalMultPlain(self, x, pt):
+        xa, xp = _u64(x)
+        pa, pp = _u64(pt)
+        out = np.zeros_like(xa)
+        _check(lib().piehip_eval_mult_plain(self._h, xp, pp, out.ctypes.data_as(u64p)))
+        return out
+
+    def EvalMult(self, x, y, relin=True):
+        xa, xp = _u64(x)
+        ya, yp = _u64(y)
+        batched = xa.ndim == 4
+        nct = xa.shape[0] if batched else 1
+        out = np.zeros((nct, 2 if relin else 3, self.L, self.N), dtype=np.uint64)
+        _check(lib().piehip_eval_mult(self._h, xp, yp, nct, int(relin), out.ctypes.data_as(u64p)))
+        return out if batched else out[0]
+
+    def EvalAutomorphism(self, x, g, rk):
+        xa, xp = _u64(x)
+        ka, kp = _u64(rk)
+        out = np.zeros_like(xa)
+        _check(lib().piehip_eval_automorph(self._h, xp, g, kp, out.ctypes.data_as(u64p)))
+        return out
+
+    def MakePackedPlaintext(self, slots):
+        s = np.ascontiguousarray(slots, dtype=np.int64)
+        single = s.ndim == 1
+        s2 = s.reshape(1, -1) if single else s
+        out = np.zeros((s2.shape[0], self.L, self.N), dtype=np.uint64)
+        _check(lib().piehip_encode(self._h, s2.ctypes.data_as(i64p), s2.shape[0], s2.shape[1], out.ctypes.data_as(u64p)))
+        return out[0] if single else out
+
+    def base_convert(self, which, polys):
+        a, ap = _u64(polys)
+        npoly = a.shape[0]
+        out = np.zeros((npoly, self.L if which == 2 else self.M, self.N), dtype=np.uint64)
+        _check(lib().piehip_base_convert(self._h, which, ap, npoly, out.ctypes.data_as(u64p)))
+        return out
+
+    def load_relin_key(self, evk):
+        a, ap = _u64(evk)
+        assert a.shape == (self.L, 2, self.L, self.N)
+        _check(lib().piehip_load_relin_key(self._h, ap))
+
+    # -- measurement
+    def set_profiling(self, on):
+        _check(lib().piehip_set_profiling(self._h, int(on)))
+
+    def profile(self):
+        n = np.zeros(NKERNELS, dtype=np.uint32)
+        ms = np.zeros(NKERNELS, dtype=np.float64)
+        by = np.zeros(NKERNELS, dtype=np.float64)
+        _check(lib().piehip_profile_read(self._h, n.ctypes.data_as(u32p), ms.ctypes.data_as(f64p), by.ctypes.data_as(f64p)))
+        names = [lib().piehip_kernel_name(k).decode() for k in range(NKERNELS)]
+        return {names[k]: dict(launches=int(n[k]), ms=float(ms[k]), alg_bytes=float(by[k])) for k in range(NKERNELS) if n[k]}
+
+
+class BatchedFHEHIPPIE:
+    """Mirror of the reference operator (BatchedFHEHIPPIE.hpp:18-49).
+
+    The reference constructor takes (cryptoContext, publicKey, HierarchicalCuckooHashTable) and packs
+    the table (BatchedFHEHIPPIE.cpp:9-86).  Here the packed database arrives either as EVALUATION
+    limbs (vectorizedHCT [K][b][E][L][N], preCalcRandomMask [b][L][N]) or as raw slot values
+    ([K][b][E][B], [b][B]) which the device encodes (MakePackedPlaintext, .cpp:68,81).
+    stash_size / multi-table flags reproduce the argument checks at .cpp:13-21.
+    """
+
+    def __init__(self, cryptoContext, vectorizedHCT=None, preCalcRandomMask=None, slots=None, mask_slots=None,
+                 serverStashSize=0, simpleMultiTables=True, cuckooMultiTables=True):
+        if serverStashSize != 0:
+            raise ValueError("Error, batched FHE PIE does not support a stash (yet).")
+        if not simpleMultiTables or not cuckooMultiTables:
+            raise ValueError("Error, batched FHE PIE currently does not support combined tables.")
+        self.cc = cryptoContext
+        h = cryptoContext._h
+        if vectorizedHCT is not None:
+            db, dbp = _u64(vectorizedHCT)
+            mk, mkp = _u64(preCalcRandomMask)
+            self.K, self.b, self.E = db.shape[0], db.shape[1], db.shape[2]
+            if db.shape[3:] != (self.cc.L, self.cc.N) or mk.shape != (self.b, self.cc.L, self.cc.N):
+                raise ValueError("database shape does not match the crypto context")
+            _check(lib().piehip_load_db(h, self.K, self.b, self.E, dbp, mkp))
+        else:
+            s = np.ascontiguousarray(slots, dtype=np.int64)
+            m = np.ascontiguousarray(mask_slots, dtype=np.int64)
+            self.K, self.b, self.E, B = s.shape
+            if m.shape != (self.b, B):
+                raise ValueError("mask shape does not match the database")
+            if np.abs(s).max(initial=0) >= self.cc.t or np.abs(m).max(initial=0) >= self.cc.t:
+                raise ValueError("slot value out of range for the plaintext modulus")
+            _check(lib().piehip_load_db_slots(h, self.K, self.b, self.E, B, s.ctypes.data_as(i64p), m.ctypes.data_as(i64p)))
+        self._keep = []
+
+    def setIndex(self, indexMatrix):
+        a, ap = _u64(indexMatrix)
+        if a.shape != (self.K, self.E, 2, self.cc.L, self.cc.N):
+            raise ValueError("index matrix must be [K][E] ciphertexts")
+        _check(lib().piehip_set_index(self.cc._h, ap))
+
+    def setMinusCompareElement(self, minusCompareElement):
+        a, ap = _u64(minusCompareElement)
+        if a.shape != (2, self.cc.L, self.cc.N):
+            raise ValueError("minus element must be one ciphertext")
+        _check(lib().piehip_set_minus(self.cc._h, ap))
+
+    def setIndexDevice(self, ptr):
+        _check(lib().piehip_set_index_device(self.cc._h, ptr))
+
+    def setMinusCompareElementDevice(self, ptr):
+        _check(lib().piehip_set_minus_device(self.cc._h, ptr))
+
+    def run(self, sync=True):
+        _check(lib().piehip_run(self.cc._h))
+        if sync:
+            _check(lib().piehip_sync(self.cc._h))
+
+    def sync(self):
+        _check(lib().piehip_sync(self.cc._h))
+
+    def getResultList(self):
+        out = np.zeros((self.b, 2, self.cc.L, self.cc.N), dtype=np.uint64)
+        _check(lib().piehip_get_results(self.cc._h, out.ctypes.data_as(u64p)))
+        return out
+
+    def resultsDevicePtr(self):
+        p = C.c_void_p()
+        _check(lib().piehip_results_device(self.cc._h, C.byref(p)))
+        return p.value

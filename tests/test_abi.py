@@ -1,0 +1,61 @@
+"""CPU-side checks of the drop-in boundary: libpiehip.so loads without a GPU and exports every
+symbol include/piehip.h declares; parameter generation agrees with the oracle; no silent CPU path."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from nested_hashing_psi_amd import build
+    return build()
+
+
+def test_library_exports_every_declared_symbol(built):
+    import ctypes
+    from nested_hashing_psi_amd._lib import SYMBOLS
+    hdr = open(os.path.join(ROOT, "include", "piehip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(piehip_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    lib = ctypes.CDLL(built)
+    for name in declared:
+        assert hasattr(lib, name), "libpiehip.so does not export %s" % name
+    assert declared == set(SYMBOLS), "python binding and header disagree: %s" % (declared ^ set(SYMBOLS))
+
+
+def test_default_moduli_match_oracle(built, ob):
+    from nested_hashing_psi_amd import pie
+    for N, L in [(4096, 2), (8192, 3), (16384, 4), (32768, 6)]:
+        q, p = pie.default_moduli(N, L)
+        oq, op_ = ob.default_moduli(N, L)
+        assert (q == oq).all() and (p == op_).all()
+    with pytest.raises(ValueError):
+        pie.default_moduli(1000, 2)
+
+
+def test_no_cpu_fallback(built):
+    """without a GPU the product refuses to create a context instead of computing on the host"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from nested_hashing_psi_amd import pie
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        pie.PieContext(4096, 2, 65537)
+
+
+def test_product_does_not_touch_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/"""
+    pkg = os.path.join(ROOT, "nested_hashing_psi_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
+                src = open(os.path.join(dirpath, f)).read()
+                for line in src.splitlines():
+                    code = line.split("//")[0].split("#")[0] if not f.endswith(".py") else line.split("#")[0]
+                    assert "pie_oracle" not in code and "libpieoracle" not in code and "from oracle" not in code \
+                        and "import oracle" not in code, "%s references the oracle: %s" % (f, line)

@@ -1,0 +1,229 @@
+"""GPU parity: libpiehip.so (through its C ABI) against the CPU oracle, bit for bit.
+
+Everything here is integer work, so the bar is exact equality of every limb word.  The oracle is
+test infrastructure (oracle/); the product path under test is nested_hashing_psi_amd -> libpiehip.so.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+T16 = 65537
+T32 = 4296540161
+
+
+@pytest.fixture(scope="module")
+def pie():
+    from nested_hashing_psi_amd import pie as p
+    return p
+
+
+def rand_limbs(rng, moduli, shape_prefix, N):
+    """uniform residues: array [*shape_prefix][len(moduli)][N]"""
+    out = np.zeros(tuple(shape_prefix) + (len(moduli), N), dtype=np.uint64)
+    for i, m in enumerate(moduli):
+        out[..., i, :] = rng.integers(0, int(m), tuple(shape_prefix) + (N,), dtype=np.uint64)
+    return out
+
+
+@pytest.mark.parametrize("N,L,t", [(64, 2, T16), (1024, 3, T32), (4096, 2, T16), (8192, 3, T32), (16384, 4, T32), (32768, 6, T32)])
+def test_tables_match_oracle(ob, pie, N, L, t):
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    assert (cc.moduli == o.moduli).all()
+    for mi in range(2 * L + 2):
+        assert cc.psi(mi) == o.psi(mi)
+    for mi in (0, 2 * L, 2 * L + 1):
+        f1, i1 = cc.twiddles(mi)
+        f2, i2 = o.twiddles(mi)
+        assert (f1[1:] == f2[1:]).all() and (i1[1:] == i2[1:]).all()
+    assert (cc.slot_positions() == o.slot_positions()).all()
+    cc.close()
+
+
+@pytest.mark.parametrize("N,L,t", [(64, 2, T16), (256, 1, T16), (1024, 3, T32), (4096, 2, T16), (8192, 3, T32), (16384, 4, T32),
+                                   (32768, 6, T32)])
+def test_ntt_bit_exact(ob, pie, N, L, t):
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(N + L)
+    M = 2 * L + 1
+    # a batch over QP (moduli cycle through all 2L+1), ragged batch count
+    x = rand_limbs(rng, o.moduli[:M], (3,), N)
+    x[0, 0, :] = 0                      # all-zero limb
+    x[0, 1, :] = o.moduli[1] - np.uint64(1)  # all q-1
+    f = cc.ntt(x, 0, M)
+    want = np.stack([np.stack([o.ntt(mi, x[k, mi]) for mi in range(M)]) for k in range(3)])
+    assert (f == want).all()
+    back = cc.ntt(f, 0, M, inverse=True)
+    assert (back == x).all()
+    # Q-only batch and the plaintext modulus
+    y = rand_limbs(rng, o.moduli[:L], (5,), N)
+    assert (cc.ntt(y, 0, L) == np.stack([np.stack([o.ntt(mi, y[k, mi]) for mi in range(L)]) for k in range(5)])).all()
+    z = rng.integers(0, t, (2, N), dtype=np.uint64)
+    assert (cc.ntt(z, M, 1, inverse=True) == np.stack([o.intt(M, z[k]) for k in range(2)])).all()
+    cc.close()
+
+
+@pytest.mark.parametrize("N,L,t", [(64, 1, T16), (256, 2, T16), (1024, 3, T32), (4096, 4, T32), (2048, 6, T32)])
+def test_base_conversions_bit_exact(ob, pie, N, L, t):
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(17 * N + L)
+    M = 2 * L + 1
+    xq = rand_limbs(rng, o.moduli[:L], (4,), N)
+    xq[0, :, 0] = 0
+    xq[0, :, 1] = o.q - np.uint64(1)
+    got = cc.base_convert(0, xq)
+    assert (got == np.stack([o.expand_q_to_qp(xq[k]) for k in range(4)])).all()
+    got = cc.base_convert(1, xq)
+    assert (got == np.stack([o.scale_pq_expand(xq[k]) for k in range(4)])).all()
+    xqp = rand_limbs(rng, o.moduli[:M], (6,), N)
+    got = cc.base_convert(2, xqp)
+    assert (got == np.stack([o.scale_round_tp(xqp[k]) for k in range(6)])).all()
+    cc.close()
+
+
+@pytest.mark.parametrize("N,L,t", [(64, 2, T16), (4096, 2, T16), (8192, 3, T32), (16384, 4, T32), (32768, 6, T32)])
+def test_eval_ops_bit_exact(ob, pie, N, L, t):
+    """EvalAdd / EvalMult(ct,pt) / EvalMult(ct,ct) with and without relinearisation, batched"""
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(N)
+    sk = o.keygen(1)
+    evk = o.relin_keygen(sk, 2)
+    cc.load_relin_key(evk)
+    nct = 3 if N <= 8192 else 2
+    lim = 150
+    xs = [rng.integers(-lim, lim, min(N, 64)) for _ in range(nct)]
+    ys = [rng.integers(-lim, lim, min(N, 64)) for _ in range(nct)]
+    cx = np.stack([o.encrypt_slots(sk, v, 10 + i) for i, v in enumerate(xs)])
+    cy = np.stack([o.encrypt_slots(sk, v, 20 + i) for i, v in enumerate(ys)])
+    pt = o.encode_eval(ys[0])
+    assert (cc.EvalAdd(cx[0], cy[0]) == o.add(cx[0], cy[0])).all()
+    assert (cc.EvalMultPlain(cx[0], pt) == o.mul_plain(cx[0], pt)).all()
+    t3 = cc.EvalMult(cx, cy, relin=False)
+    assert (t3 == np.stack([o.mul_tensor(cx[i], cy[i]) for i in range(nct)])).all()
+    r2 = cc.EvalMult(cx, cy, relin=True)
+    assert (r2 == np.stack([o.mul(cx[i], cy[i], evk) for i in range(nct)])).all()
+    dec, budget = o.decrypt_slots(sk, r2[1], len(xs[1]))
+    assert budget > 0 and (dec == xs[1] * ys[1]).all()
+    cc.close()
+
+
+@pytest.mark.parametrize("N,L,t", [(64, 2, T16), (4096, 2, T16), (16384, 4, T32)])
+def test_encode_bit_exact(ob, pie, N, L, t):
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(5)
+    for B in (1, 7, N // 2, N):
+        s = rng.integers(-(t // 2), t // 2, (3, B), dtype=np.int64)
+        s[0, 0] = 0
+        got = cc.MakePackedPlaintext(s)
+        assert (got == np.stack([o.encode_eval(s[k]) for k in range(3)])).all()
+    with pytest.raises(ValueError):
+        cc.MakePackedPlaintext(np.array([t], dtype=np.int64))
+    cc.close()
+
+
+def test_automorphism_kat1(ob, pie):
+    """tests/TestOpenFHE.cpp:36,62-65: rotate [1..12] by +-1, +-2 (A9; not on the batched path)"""
+    N, L, t = 4096, 2, T16
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    sk = o.keygen(3)
+    v1 = np.arange(1, 13)
+    c1 = o.encrypt_slots(sk, v1, 1)
+    for r in (1, 2, -1, -2):
+        g = o.rot_index(r)
+        rk = o.rot_keygen(sk, g, 50 + r)
+        got = cc.EvalAutomorphism(c1, g, rk)
+        assert (got == o.automorph(c1, g, rk)).all()
+        dec, budget = o.decrypt_slots(sk, got, 12)
+        full = np.zeros(N // 2, dtype=np.int64)
+        full[:12] = v1
+        assert budget > 0 and (dec == np.roll(full, -r)[:12]).all()
+    with pytest.raises(ValueError):
+        cc.EvalAutomorphism(c1, 4, rk)
+    cc.close()
+
+
+def _query(ob, o, rng, nS, nC, k, e, K, E, b, hash_seed=987654321):
+    from tests.test_oracle_pie import distinct_items
+    universe = distinct_items(rng, o.t, nS + nC)
+    server = universe[:nS].copy()
+    ninter = nC // 2 + 1
+    client = np.concatenate([server[:ninter], universe[nS:nS + nC - ninter]])
+    rng.shuffle(client)
+    tab = ob.Tabulation(hash_seed, k + K)
+    tbl = ob.hct_build(tab, server, k, e, K, b, E, evict_seed=1)
+    ob.hct_shuffle_bins(tbl, 2)
+    slots = ob.pack_db(tbl)
+    mk = ob.masks(o.t, b, k * e, 3)
+    ctab = ob.client_build(tab, client, k, e, evict_seed=4)
+    index, minus = ob.client_vectors(tab, ctab, K, E)
+    return dict(server=server, client=client, inter=server[:ninter], slots=slots, mask_slots=mk, ctab=ctab, index=index,
+                minus=minus)
+
+
+@pytest.mark.parametrize("N,L,t,nS,nC,k,e,K,E,b", [
+    (4096, 2, T16, 100, 1, 2, 1, 2, 10, 20),      # KAT-0 shape (TestBatchedFHEPIE.cpp:89-94)
+    (4096, 2, T16, 300, 16, 2, 12, 2, 6, 6),
+    (2048, 3, T32, 500, 24, 3, 10, 2, 8, 5),
+    (1024, 4, T32, 200, 10, 2, 8, 3, 6, 4),       # K = 3: chained ct x ct
+    (8192, 3, T32, 2000, 64, 3, 40, 2, 8, 7),
+    (1024, 2, T16, 60, 4, 2, 3, 2, 5, 1),         # a single bin layer
+])
+def test_run_bit_exact_and_semantics(ob, pie, N, L, t, nS, nC, k, e, K, E, b):
+    """BatchedFHEHIPPIE::run() on the GPU == the oracle's restated run(), and the decrypted result
+    is the intersection (PSIClient.hpp:142-164)"""
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(N + nS)
+    sk = o.keygen(11)
+    evk = o.relin_keygen(sk, 12)
+    d = _query(ob, o, rng, nS, nC, k, e, K, E, b)
+    B = k * e
+    db = np.stack([o.encode_eval(d["slots"][h, bn, j]) for h in range(K) for bn in range(b) for j in range(E)]).reshape(K, b, E, L, N)
+    masks = np.stack([o.encode_eval(d["mask_slots"][bn]) for bn in range(b)])
+    idx = np.stack([o.encrypt_slots(sk, d["index"][h, j], 100 + h * E + j) for h in range(K) for j in range(E)]).reshape(K, E, 2, L, N)
+    minus = o.encrypt_slots(sk, d["minus"], 99)
+    cc.load_relin_key(evk)
+    # (a) database handed over as EVALUATION limbs
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    op.setMinusCompareElement(minus)
+    op.setIndex(idx)
+    op.run()
+    got = op.getResultList()
+    want = o.pie_run(idx, minus, db, masks, evk)
+    assert (got == want).all()
+    # (b) database handed over as raw slot values, encoded on the device
+    op2 = pie.BatchedFHEHIPPIE(cc, slots=d["slots"], mask_slots=d["mask_slots"])
+    op2.setMinusCompareElement(minus)
+    op2.setIndex(idx)
+    op2.run()
+    assert (op2.getResultList() == want).all()
+    # run() is repeatable (same inputs -> same ciphertexts), as the server calls it once per query
+    op2.run()
+    assert (op2.getResultList() == want).all()
+    dec = np.stack([o.decrypt_slots(sk, got[bn], B)[0] for bn in range(b)])
+    found = ob.client_scan(d["ctab"], dec)
+    assert sorted(int(v) for v in found) == sorted(int(v) for v in d["inter"])
+    cc.close()
+
+
+def test_error_behaviour(ob, pie):
+    """argument checks of the reference: BatchedFHEHIPPIE.cpp:13-21 (invalid_argument), call order"""
+    cc = pie.PieContext(1024, 2, T16)
+    with pytest.raises(ValueError, match="stash"):
+        pie.BatchedFHEHIPPIE(cc, slots=np.zeros((2, 1, 1, 4), dtype=np.int64), mask_slots=np.ones((1, 4), dtype=np.int64), serverStashSize=1)
+    with pytest.raises(ValueError, match="combined tables"):
+        pie.BatchedFHEHIPPIE(cc, slots=np.zeros((2, 1, 1, 4), dtype=np.int64), mask_slots=np.ones((1, 4), dtype=np.int64), cuckooMultiTables=False)
+    op = pie.BatchedFHEHIPPIE(cc, slots=np.zeros((2, 1, 1, 4), dtype=np.int64), mask_slots=np.ones((1, 4), dtype=np.int64))
+    with pytest.raises(RuntimeError):
+        op.run()  # no key, no inputs
+    with pytest.raises(ValueError):
+        pie.PieContext(1000, 2, T16)  # N not a power of two
+    with pytest.raises(ValueError):
+        pie.PieContext(1024, 2, 65539)  # t not 1 mod 2N / not prime
+    cc.close()

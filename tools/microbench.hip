@@ -1,0 +1,111 @@
+// microbench.hip -- integer ALU throughput probes for gfx950 (which 64-bit modmul formulation is
+// cheapest?).  Stand-alone: hipcc --offload-arch=gfx950 -O3 -o microbench microbench.hip
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+typedef uint64_t u64;
+typedef uint32_t u32;
+#define ITER 4096
+#define CH 8
+
+template <int OP>
+__global__ void __launch_bounds__(256) probe(u64 *out, u64 seed, u64 q, u64 w, u64 wsh)
+{
+    u64 x[CH];
+    for (int c = 0; c < CH; c++) x[c] = seed * (threadIdx.x + 1 + c * 977) + blockIdx.x;
+    u32 lo32 = (u32)seed | 1, hi32 = (u32)(seed >> 13) | 1;
+    double dq = (double)(q >> 12), dinv = 1.0 / dq;
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            if (OP == 0) {  // 32x32->64 mad (v_mad_u64_u32)
+                x[c] = (u64)(u32)x[c] * lo32 + x[c];
+            } else if (OP == 1) {  // v_mul_lo_u32
+                x[c] = (u32)((u32)x[c] * lo32 + hi32);
+            } else if (OP == 2) {  // v_mul_hi_u32
+                x[c] = __umulhi((u32)x[c], lo32) + hi32;
+            } else if (OP == 3) {  // 64-bit mulhi
+                x[c] = __umul64hi(x[c], wsh) + w;
+            } else if (OP == 4) {  // 64-bit mullo
+                x[c] = x[c] * w + wsh;
+            } else if (OP == 5) {  // Shoup lazy modmul
+                x[c] = x[c] * w - __umul64hi(x[c], wsh) * q;
+            } else if (OP == 6) {  // Harvey butterfly (pairs of chains)
+                if (c & 1) {
+                    u64 u = x[c - 1], v = x[c];
+                    u = u >= 2 * q ? u - 2 * q : u;
+                    u64 t = v * w - __umul64hi(v, wsh) * q;
+                    x[c - 1] = u + t;
+                    x[c] = u - t + 2 * q;
+                }
+            } else if (OP == 7) {  // 64-bit add
+                x[c] = x[c] + w + (x[c] >> 7);
+            } else if (OP == 8) {  // f64 fma
+                double d = __longlong_as_double(x[c]);
+                d = fma(d, dinv, dq);
+                x[c] = __double_as_longlong(d);
+            } else if (OP == 9) {  // full 128-bit product accumulate (mac128)
+                u64 lo = x[c] * w, hi = __umul64hi(x[c], w);
+                x[c] = lo + hi;
+            } else if (OP == 10) {  // v_mul_u32_u24
+                x[c] = __umul24((u32)x[c], lo32) + hi32;
+            } else if (OP == 11) {  // Solinas-style: q = 2^60 - delta, delta < 2^24: reduce 128-bit product without w'
+                u64 lo = x[c] * w, hi = __umul64hi(x[c], w);
+                u64 delta = (1ULL << 60) - q;
+                u64 zh = (hi << 4) | (lo >> 60), zl = lo & ((1ULL << 60) - 1);  // z = zh*2^60 + zl
+                // zh*delta (zh < 2^62, delta < 2^24) -> up to 86 bits
+                u64 p_lo = zh * delta, p_hi = __umul64hi(zh, delta);
+                u64 s = zl + (p_lo & ((1ULL << 60) - 1));
+                u64 top = (p_hi << 4) | (p_lo >> 60);
+                x[c] = s + top * delta;
+            }
+        }
+    }
+    u64 r = 0;
+    for (int c = 0; c < CH; c++) r ^= x[c];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
+template <int OP>
+static void run(const char *name, double ops_per_iter_chain, u64 *d)
+{
+    const int blocks = 256 * 8;
+    u64 q = (1ULL << 60) - 33 * 32768 + 1, w = 0x0123456789abcdefULL % q, wsh = (u64)(((unsigned __int128)w << 64) / q);
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    hipLaunchKernelGGL(probe<OP>, dim3(blocks), dim3(256), 0, 0, d, 0x9E3779B97F4A7C15ULL, q, w, wsh);
+    hipDeviceSynchronize();
+    hipEventRecord(a, 0);
+    for (int r = 0; r < 5; r++) hipLaunchKernelGGL(probe<OP>, dim3(blocks), dim3(256), 0, 0, d, 0x9E3779B97F4A7C15ULL + r, q, w, wsh);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    double total = 5.0 * blocks * 256 * (double)ITER * CH * ops_per_iter_chain;
+    double gops = total / (ms * 1e-3) / 1e9;
+    // lanes per clock per CU at 2.4 GHz (256 CUs)
+    double per_cu_clk = gops * 1e9 / 256 / 2.4e9;
+    printf("%-28s %8.3f ms  %10.1f Gop/s  %7.2f lane-ops/clk/CU  (%.1f cyc per wave64 op per SIMD)\n", name, ms / 5, gops,
+           per_cu_clk, 64.0 * 4 / per_cu_clk);
+}
+
+int main()
+{
+    u64 *d;
+    hipMalloc((void **)&d, 256 * 8 * 256 * 8);
+    run<0>("mad_u64_u32", 1, d);
+    run<1>("mul_lo_u32", 1, d);
+    run<2>("mul_hi_u32", 1, d);
+    run<10>("mul_u32_u24", 1, d);
+    run<3>("umul64hi(+add)", 1, d);
+    run<4>("mul64lo(+add)", 1, d);
+    run<9>("mul128 (lo+hi)", 1, d);
+    run<5>("shoup_lazy modmul", 1, d);
+    run<6>("harvey butterfly", 0.5, d);
+    run<11>("solinas modmul", 1, d);
+    run<7>("add64 x2 + shift", 1, d);
+    run<8>("fma_f64", 1, d);
+    hipFree(d);
+    return 0;
+}
