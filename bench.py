@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- server-side batched-FHE PIE throughput on MI355X.
+
+One "step" = one BatchedFHEHIPPIE::run() (reference BatchedFHEHIPPIE.cpp:88-129; what the server
+times at src/Server/FHE/BatchedFHEPSIServer.cpp:98-106) over one synthetic query, inputs already
+resident in HBM.  Metric: result ciphertexts per second (b / t_run), whole job.
+
+  python bench.py --gpus 1 --steps K --warmup W            (N=1: config C3 of BASELINE.json)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: bin layers are independent, so every rank owns a shard of bin layers
+(weak scaling: each rank evaluates the b layers of its own |S|=2^20 server shard against the same
+query); the only collective is the final RCCL all-gather of the result ciphertexts.
+
+Synthetic data: the arithmetic is data-independent, so index/minus ciphertexts and the
+relinearisation key are uniform residues (what real ones are indistinguishable from) and the
+database is uniform slot values packed on the device.  Correctness is the tests' job
+(tests/test_gpu_parity.py), not this script's; --verify runs one real query through the oracle.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: N, L, t, k, e, K, E, b, |S|, |C|   
+    "C1": dict(N=4096, L=2, t=65537, k=3, e=110, K=2, E=7, b=7, S=1 << 12, C=1 << 8),
+    "C2": dict(N=8192, L=3, t=4296540161, k=3, e=443, K=2, E=12, b=12, S=1 << 16, C=1 << 10),
+    "C3": dict(N=16384, L=4, t=4296540161, k=2, e=4949, K=2, E=14, b=14, S=1 << 20, C=1 << 10),
+    "C5": dict(N=32768, L=6, t=4296540161, k=2, e=13004, K=3, E=30, b=30, S=1 << 24, C=1 << 12),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
+
+
+def uniform_limbs(torch, shape_prefix, moduli, N, device, gen):
+    """uniform residues [*shape_prefix][len(moduli)][N] as int64 (bit pattern of the uint64 limbs)"""
+    out = torch.empty(tuple(shape_prefix) + (len(moduli), N), dtype=torch.int64, device=device)
+    for i, m in enumerate(moduli):
+        out[..., i, :] = torch.randint(0, int(m), tuple(shape_prefix) + (N,), dtype=torch.int64, device=device, generator=gen)
+    return out
+
+
+def cpu_baseline(cfg, seconds_target=12.0):
+    """The oracle (a CPU restatement of the reference path -- OpenFHE itself is not available)
+    timed on this host, one core, on a bounded sample of the same workload."""
+    from oracle import binding as ob
+    N, L, t, K, E, b = cfg["N"], cfg["L"], cfg["t"], cfg["K"], cfg["E"], cfg["b"]
+    o = ob.Oracle(N, L, t)
+    rng = np.random.default_rng(1)
+
+    def rl(shape):
+        out = np.zeros(shape + (L, N), dtype=np.uint64)
+        for i in range(L):
+            out[..., i, :] = rng.integers(0, int(o.q[i]), shape + (N,), dtype=np.uint64)
+        return out
+
+    idx, minus, evk = rl((K, E, 2)), rl((2,)), rl((L, 2))
+    # time one bin layer first, then as many bin layers as fit the target (bin layers are independent
+    # and cost the same, BatchedFHEHIPPIE.cpp:91)
+    db1, m1 = rl((K, 1, E)), rl((1,))
+    t0 = time.perf_counter()
+    o.pie_run(idx, minus, db1, m1, evk)
+    per_bin = time.perf_counter() - t0
+    nb = int(max(1, min(64 * b, seconds_target / per_bin)))
+    done, t0 = 0, time.perf_counter()
+    while done < nb:
+        o.pie_run(idx, minus, db1, m1, evk)
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "ciphertexts/s", "cores": 1, "kind": "port",
+            "sample": "%d bin layers of the %s workload (K=%d, E=%d; 1 ct x ct + %d ct x pt MACs each), %.1f s; "
+                      "CPU restatement in C (oracle/), OpenFHE not available" % (done, cfg["name"], K, E, K * E, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+    from nested_hashing_psi_amd import pie
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the PIE hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+
+    cfg = dict(CONFIGS[args.config], name=args.config)
+    N, L, t, K, E, b = cfg["N"], cfg["L"], cfg["t"], cfg["K"], cfg["E"], cfg["b"]
+    B = cfg["k"] * cfg["e"]
+    if args.scaling == "strong" and world > 1:
+        lo = (b * rank) // world
+        hi = (b * (rank + 1)) // world
+        b_local = hi - lo
+    else:
+        b_local = b
+    b_total = b_local * world if args.scaling == "weak" else b
+
+    stream = torch.cuda.current_stream(device)
+    cc = pie.PieContext(N, L, t, device=local_rank, stream=stream.cuda_stream)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(123456789 + rank)
+    rng = np.random.default_rng(987654321 + rank)
+    # relinearisation key and per-query inputs: resident in HBM before the timed region
+    evk = uniform_limbs(torch, (L, 2), cc.q, N, device, gen)
+    idx = uniform_limbs(torch, (K, E, 2), cc.q, N, device, gen)
+    minus = uniform_limbs(torch, (2,), cc.q, N, device, gen)
+    cc.load_relin_key(evk.cpu().numpy().view(np.uint64))
+    op = None
+    if b_local > 0:
+        slots = rng.integers(0, t, (K, b_local, E, B), dtype=np.int64)
+        slots[slots > t // 2] -= t
+        mask_slots = rng.integers(1, t, (b_local, B), dtype=np.int64)
+        mask_slots[mask_slots > t // 2] -= t
+        op = pie.BatchedFHEHIPPIE(cc, slots=slots, mask_slots=mask_slots)  # packed + NTT'd on the device
+        op.setIndexDevice(idx.data_ptr())
+        op.setMinusCompareElementDevice(minus.data_ptr())
+    ct_words = 2 * L * N
+    gathered = None
+    my_out = torch.zeros((max(b_local, 1), ct_words), dtype=torch.int64, device=device)
+    if world > 1:
+        bmax = -(-b // world) if args.scaling == "strong" else b_local
+        my_out = torch.zeros((bmax, ct_words), dtype=torch.int64, device=device)
+        gathered = torch.empty((world * bmax, ct_words), dtype=torch.int64, device=device)
+
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def step():
+        if op is not None:
+            op.run(sync=False)
+        if world > 1:
+            if op is not None:
+                # results -> the gather buffer (device-to-device on the same stream), then RCCL all-gather
+                hip.hipMemcpyAsync(ctypes.c_void_p(my_out.data_ptr()), ctypes.c_void_p(op.resultsDevicePtr()),
+                                   ctypes.c_size_t(b_local * ct_words * 8), 3, ctypes.c_void_p(stream.cuda_stream))
+            dist.all_gather_into_tensor(gathered, my_out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(device)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # per-kernel times of the same run(), HIP events on the launch stream (separate, untimed passes)
+    roofline = None
+    kernels = {}
+    if op is not None and rank == 0:
+        cc.set_profiling(True)
+        agg = {}
+        for _ in range(max(1, args.profile_steps)):
+            op.run(sync=True)
+            for name, rec in cc.profile().items():
+                a = agg.setdefault(name, dict(launches=0, ms=0.0, alg_bytes=0.0))
+                for key in a:
+                    a[key] += rec[key]
+        cc.set_profiling(False)
+        for name, a in agg.items():
+            kernels[name] = dict(launches_per_step=a["launches"] / args.profile_steps, us_per_step=1e3 * a["ms"] / args.profile_steps,
+                                 alg_GBps=a["alg_bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else None)
+        ntt_ms = sum(agg[n]["ms"] for n in ("ntt_fwd", "ntt_inv") if n in agg)
+        ntt_bytes = sum(agg[n]["alg_bytes"] for n in ("ntt_fwd", "ntt_inv") if n in agg)
+        ntt_launch = sum(agg[n]["launches"] for n in ("ntt_fwd", "ntt_inv") if n in agg)
+        if ntt_ms > 0:
+            ach = ntt_bytes / (ntt_ms * 1e-3) / 1e9
+            roofline = {"kernel": "ntt (forward+inverse, LDS-resident limb)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_us": 1e3 * ntt_ms / ntt_launch, "alg_bytes_per_launch": ntt_bytes / ntt_launch,
+                        "launches_per_step": ntt_launch / args.profile_steps}
+
+    if rank == 0:
+        value = b_total / (ms_per_step * 1e-3)
+        line = {
+            "metric": "server PIE ciphertexts/sec", "value": value, "unit": "ciphertexts/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%s: BatchedFHEHIPPIE::run(), N=%d, %d RNS primes (60-bit), t=%d, |S|=2^%d |C|=2^%d, k=%d e=%d (B=%d slots), "
+                                   "K=%d E=%d b=%d bin layers per GPU; %d ct x pt MACs + %d ct x ct (HPS + BV relin) + %d mask mults per GPU per step"
+                                   % (args.config, N, L, t, cfg["S"].bit_length() - 1, cfg["C"].bit_length() - 1, cfg["k"], cfg["e"], B, K, E,
+                                      b_local, b_local * K * E, b_local * (K - 1), b_local),
+                       "result_ciphertexts_per_step": b_total, "parallelism": "bins%d" % world,
+                       "collective": "rccl all_gather of results" if world > 1 else "none"},
+            "mac_per_s": b_total * K * E / (ms_per_step * 1e-3),
+            "roofline": roofline, "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+            line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    cc.close()
+
+
+if __name__ == "__main__":
+    main()

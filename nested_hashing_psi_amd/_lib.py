@@ -56,6 +56,15 @@ def lib():
             raise RuntimeError(
                 "libpiehip.so is not built (%s). Run nested_hashing_psi_amd.build(); "
                 "there is no CPU fallback for the PIE hot path." % LIB_PATH)
+        # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64 (same soname as
+        # /opt/rocm's).  If libpiehip.so were loaded first it would bind the system copy and a later
+        # `import torch` would bring a second runtime into the process, which then finds no device.
+        # Importing torch first makes the loader resolve libpiehip's libamdhip64.so.7 to the copy
+        # torch already mapped (torch is only plumbing here: streams, device tensors, RCCL).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)  # AttributeError if the library does not export it

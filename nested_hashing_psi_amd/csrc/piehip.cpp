@@ -245,9 +245,11 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
         return fail(PIEHIP_EINVAL, err);
     }
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev <= 0) {
         delete h;
-        return fail(PIEHIP_EHIP, "no HIP device visible: libpiehip has no CPU fallback");
+        return fail(PIEHIP_EHIP, std::string("no HIP device visible (hipGetDeviceCount: ") + hipGetErrorString(de) + ", " +
+                                     std::to_string(ndev) + " devices): libpiehip has no CPU fallback");
     }
     h->device = device;
 #define CHK_(expr)                                                                          \

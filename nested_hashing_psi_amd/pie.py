@@ -60,7 +60,10 @@ class PieContext:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().piehip_destroy(self._h)
+            try:
+                lib().piehip_destroy(self._h)
+            except TypeError:  # interpreter shutdown: module globals already cleared
+                pass
             self._h = None
 
     def __del__(self):

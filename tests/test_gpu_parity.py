@@ -170,9 +170,9 @@ def _query(ob, o, rng, nS, nC, k, e, K, E, b, hash_seed=987654321):
     (4096, 2, T16, 100, 1, 2, 1, 2, 10, 20),      # KAT-0 shape (TestBatchedFHEPIE.cpp:89-94)
     (4096, 2, T16, 300, 16, 2, 12, 2, 6, 6),
     (2048, 3, T32, 500, 24, 3, 10, 2, 8, 5),
-    (1024, 4, T32, 200, 10, 2, 8, 3, 6, 4),       # K = 3: chained ct x ct
+    (1024, 4, T32, 200, 10, 2, 12, 3, 6, 4),      # K = 3: chained ct x ct
     (8192, 3, T32, 2000, 64, 3, 40, 2, 8, 7),
-    (1024, 2, T16, 60, 4, 2, 3, 2, 5, 1),         # a single bin layer
+    (1024, 2, T16, 12, 4, 2, 3, 2, 5, 1),         # a single bin layer
 ])
 def test_run_bit_exact_and_semantics(ob, pie, N, L, t, nS, nC, k, e, K, E, b):
     """BatchedFHEHIPPIE::run() on the GPU == the oracle's restated run(), and the decrypted result
