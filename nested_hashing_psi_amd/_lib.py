@@ -42,6 +42,7 @@ SYMBOLS = {
     "piehip_eval_automorph": (C.c_int, [C.c_void_p, u64p, C.c_uint32, u64p, u64p]),
     "piehip_encode": (C.c_int, [C.c_void_p, i64p, C.c_uint32, C.c_uint32, u64p]),
     "piehip_base_convert": (C.c_int, [C.c_void_p, C.c_int, u64p, C.c_uint32, u64p]),
+    "piehip_bench_ntt": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, f64p]),
     "piehip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "piehip_profile_read": (C.c_int, [C.c_void_p, u32p, f64p, f64p]),
 }
@@ -52,10 +53,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("PIEHIP_LIB", LIB_PATH)  # experiment builds (tools/) may point elsewhere
+        if not os.path.exists(path):
             raise RuntimeError(
                 "libpiehip.so is not built (%s). Run nested_hashing_psi_amd.build(); "
-                "there is no CPU fallback for the PIE hot path." % LIB_PATH)
+                "there is no CPU fallback for the PIE hot path." % path)
         # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64 (same soname as
         # /opt/rocm's).  If libpiehip.so were loaded first it would bind the system copy and a later
         # `import torch` would bring a second runtime into the process, which then finds no device.
@@ -65,7 +67,7 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)  # AttributeError if the library does not export it
             f.restype = res

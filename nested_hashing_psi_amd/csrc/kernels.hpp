@@ -10,12 +10,17 @@ namespace piehip {
 // Device-resident NTT tables: for modulus a, tables + a*4*N holds tw | tw_sh | itw | itw_sh (N each).
 struct NttPlan {
     const u64 *tables;
+    const u64 *twp;       // interleaved {w, w_shoup} pairs: per modulus [fwd N pairs][inv N pairs]
     const DevConsts *dc;  // device pointer
     u32 N, logN;
+    u32 num_cus;
+    bool force_generic;   // tests: route every size through the radix-2 LDS kernel
 };
 
 // In-place negacyclic NTT over `nlimbs` limbs [nlimbs][N]; limb i uses modulus mod_base + i % mod_count.
 // (replaces DCRTPoly::SetFormat under BatchedFHEHIPPIE.cpp:123)
+bool launch_ntt_fast(const u64 *twp, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
+                     u32 mod_count, bool inverse, u32 num_cus, hipStream_t st);
 void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, hipStream_t st);
 
 // Stage A: acc[b][K][2][L][N] = sum_j idx[h][j] (.) db[h][beta][j] + minus    (BatchedFHEHIPPIE.cpp:101-116)

@@ -162,12 +162,15 @@ void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_
         g_attr_set[inverse ? 1 : 0] = true;
     }
     const dim3 ggrid((pl.N / 2 + 255) / 256, nlimbs);
+    const bool fast_ok = !pl.force_generic && pl.twp && pl.logN - a.s0 >= 12;
     if (!inverse) {
         for (u32 ms = 1; ms < (1u << a.s0); ms <<= 1)
             hipLaunchKernelGGL(ntt_global_stage<false>, ggrid, dim3(256), 0, st, a, ms, 0u);
-        hipLaunchKernelGGL(ntt_lds_generic<false>, dim3(nlimbs << a.s0), dim3(threads), lds, st, a);
+        if (!(fast_ok && launch_ntt_fast(pl.twp, pl.dc, pl.N, pl.logN, a.s0, data, nlimbs, mod_base, mod_count, false, pl.num_cus, st)))
+            hipLaunchKernelGGL(ntt_lds_generic<false>, dim3(nlimbs << a.s0), dim3(threads), lds, st, a);
     } else {
-        hipLaunchKernelGGL(ntt_lds_generic<true>, dim3(nlimbs << a.s0), dim3(threads), lds, st, a);
+        if (!(fast_ok && launch_ntt_fast(pl.twp, pl.dc, pl.N, pl.logN, a.s0, data, nlimbs, mod_base, mod_count, true, pl.num_cus, st)))
+            hipLaunchKernelGGL(ntt_lds_generic<true>, dim3(nlimbs << a.s0), dim3(threads), lds, st, a);
         for (u32 ms = (1u << a.s0) >> 1; ms >= 1; ms >>= 1)
             hipLaunchKernelGGL(ntt_global_stage<true>, ggrid, dim3(256), 0, st, a, ms, ms == 1 ? 1u : 0u);
     }

@@ -1,0 +1,385 @@
+// kernels_ntt_fast.hip -- register-blocked negacyclic NTT for slices of 2^12 .. 2^14 coefficients.
+//
+// One persistent workgroup of T = n/32 threads walks over limbs; each thread owns 32 coefficients
+// (64 VGPRs) and the transform runs as three register passes with two LDS transposes between them:
+//
+//   forward (Cooley-Tukey)   pass A: 4 stages, thread holds rows k (stride n/16) of a column PAIR
+//                                    (2 tau, 2 tau + 1): loaded straight from HBM with 16-byte lanes;
+//                                    twiddles depend on k only -> scalar loads
+//                            pass B: 5 stages inside blocks of n/16, stride n/512
+//                            pass C: log2(n) - 9 stages inside 32 contiguous coefficients
+//   inverse (Gentleman-Sande) is the mirror image: C', B', A', then the N^-1 scaling.
+//
+// HBM traffic is exactly one coalesced read and one coalesced write of the limb (16 n bytes).  The
+// next limb's loads are issued before the current limb's passes start, so with a single resident
+// workgroup per CU (a 2^14 limb fills 136 of the 160 KiB LDS) HBM latency still hides behind ALU work.
+// LDS image: element e lives at e + 2 (e >> 5) (a 16-byte pad per 32 elements): the 32-contiguous
+// pass-C rows (ds_read_b128, lane stride 272 B), the stride-n/512 pass-B columns and the pair-wise
+// pass-A rows are all bank-conflict-free or at worst 2-way.
+//
+// The ALU, not HBM, bounds this kernel: a 60-bit Shoup butterfly is ~10 v_mad_u64_u32 plus ~10 32-bit
+// adds/selects, 7 butterflies per 16 bytes moved (DESIGN.md "NTT roofline").
+#include "kernels.hpp"
+
+namespace piehip {
+
+struct NttFastArgs {
+    u64 *data;
+    const u64 *twp;  // interleaved {w, w_shoup} pairs: per modulus 2 tables (fwd, inv) of N pairs
+    const DevConsts *dc;
+    u32 N, logN;
+    u32 s0;       // log2 slices per limb (stages below 2^s0 groups were done in global memory)
+    u32 nitems;   // limbs << s0
+    u32 mod_base, mod_count;
+};
+
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32 phi(u32 e) { return e + 2 * (e >> 5); }
+
+// ---- 60-bit Shoup multiplication on the 32-bit multiplier ------------------------------------------
+// v_mad_u64_u32 (32x32+64 -> 64) issues at twice the rate of v_mul_lo_u32 / v_mul_hi_u32 on gfx950, and
+// hipcc narrows every 64-bit product whose high half is unused to v_mul_lo_u32; inline asm keeps
+// the whole butterfly on the mad.  9 mads per modular multiplication:
+//   quotient estimate  qe = floor(b ws / 2^64) - {0,1,2}   from 3 partial products (b_lo ws_lo dropped)
+//   remainder          b w + qe (2^64 - q)  mod 2^64       as two accumulation chains (low word, cross terms)
+// The result lies in [0, 4q); with q < 2^60 the butterflies keep residues in [0, 8q) (forward) or
+// [0, 4q) (inverse) and normalise once at the end of the transform.
+__device__ __forceinline__ u64 mad_u(u32 a, u32 b, u64 c)
+{
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ u64 mul_u(u32 a, u32 b)
+{
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
+    return d;
+}
+// b < 2^64, w < q, ws = floor(w 2^64 / q), nq = 2^64 - q: returns b w mod q + {0,1,2,3} q
+__device__ __forceinline__ u64 shoup4(u64 b, u64 w, u64 ws, u64 nq)
+{
+    const u32 bl = (u32)b, bh = (u32)(b >> 32), wl = (u32)w, wh = (u32)(w >> 32);
+    const u32 sl = (u32)ws, sh = (u32)(ws >> 32), nql = (u32)nq, nqh = (u32)(nq >> 32);
+    const u64 m1 = mul_u(bl, sh);
+    const u64 m2 = mad_u(bh, sl, m1 >> 32);
+    const u64 qe = mad_u(bh, sh, m2 >> 32);
+    u64 acc = mul_u((u32)qe, nql);
+    acc = mad_u(bl, wl, acc);
+    u64 c = mul_u((u32)qe, nqh);
+    c = mad_u((u32)(qe >> 32), nql, c);
+    c = mad_u(bl, wh, c);
+    c = mad_u(bh, wl, c);
+    return acc + ((u64)(u32)c << 32);
+}
+
+// Harvey butterflies on lazy residues ---------------------------------------------------------------
+// forward: inputs in [0, 8q), outputs in [0, 8q)
+__device__ __forceinline__ void ct_bfly(u64 &a, u64 &b, u64 w, u64 ws, u64 nq, u64 q4)
+{
+    const u64 u = a >= q4 ? a - q4 : a;
+    const u64 v = shoup4(b, w, ws, nq);
+    a = u + v;
+    b = u - v + q4;
+}
+// inverse: inputs in [0, 4q), outputs in [0, 4q)
+__device__ __forceinline__ void gs_bfly(u64 &a, u64 &b, u64 w, u64 ws, u64 nq, u64 q4)
+{
+    const u64 s = a + b;
+    const u64 d = a - b + q4;
+    a = s >= q4 ? s - q4 : s;
+    b = shoup4(d, w, ws, nq);
+}
+
+// keeps hipcc from interleaving more than a few butterflies (each carries ~12 VGPRs of temporaries)
+#ifndef FENCE_EVERY
+#define FENCE_EVERY 16
+#endif
+#define BFLY_FENCE(cnt, every)                                         \
+    do {                                                               \
+        if (((cnt) % (every)) == (every) - 1) __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+
+template <int LOGN, bool INV>
+__global__ void __launch_bounds__((1 << LOGN) / 32)
+ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const DevConsts *__restrict__ gdc, NttFastArgs a)
+{
+    constexpr u32 n = 1u << LOGN;   // coefficients in this slice
+    constexpr u32 T = n / 32;       // threads
+    constexpr u32 NB = n / 16;      // pass-B block size = pass-A row stride
+    constexpr u32 SB = NB / 32;     // pass-B stride
+    constexpr int C = LOGN - 9;     // pass-C stages
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+
+    const u32 tau = threadIdx.x;
+    const u32 beta = tau / SB, rho = tau % SB;
+    u64 x[32], y[32];
+
+    u32 item = blockIdx.x;
+    if (item >= a.nitems) return;
+    // prefetch the first slice (A-layout addresses are also the coalesced copy-in/out order)
+    {
+        const u64 *g = gdata + (size_t)item * n;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u64x2 v = *reinterpret_cast<const u64x2 *>(g + 2 * tau + NB * k);
+            y[2 * k] = v.x;
+            y[2 * k + 1] = v.y;
+        }
+    }
+    for (; item < a.nitems; item += gridDim.x) {
+#pragma unroll
+        for (int k = 0; k < 32; k++) x[k] = y[k];
+        const u32 next = item + gridDim.x;
+        // forward: the next slice's loads fly during the whole transform (pass A has scalar twiddles, so
+        // the 64 extra VGPRs fit); inverse: they are issued before pass A' instead (see below)
+#ifdef NTT_EXP_NOLOAD
+        if (!INV && next < a.nitems && tau == 1000) {
+#else
+        if (!INV && next < a.nitems) {
+#endif
+            const u64 *gn = gdata + (size_t)next * n;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const u64x2 v = *reinterpret_cast<const u64x2 *>(gn + 2 * tau + NB * k);
+                y[2 * k] = v.x;
+                y[2 * k + 1] = v.y;
+            }
+        }
+        const u32 limb = item >> a.s0, blk = item & ((1u << a.s0) - 1);
+        const u32 mod = a.mod_base + limb % a.mod_count;
+        const Mod m = gdc->mod[mod];
+        const u64 q = m.q, q2 = 2 * m.q, q4 = 4 * m.q, nq = 0 - m.q;
+        // twiddle pairs of this modulus and direction; global group index of local group i at a stage
+        // with ml local groups: (ml << s0) + blk * ml + i
+        const u64x2 *__restrict__ tw = gtw + ((size_t)mod * 2 + (INV ? 1 : 0)) * a.N;
+        u64 *g = gdata + (size_t)item * n;
+
+        if (!INV) {
+            // ---- pass A: stages with 1, 2, 4, 8 local groups; rows k, k + d ------------------------
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const int d = 8 >> s;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (k & d) continue;
+                    const u32 ml = 1u << s, i = (u32)k >> (4 - s);
+                    const u64x2 w = tw[(ml << a.s0) + blk * ml + i];  // uniform: scalar load
+#pragma unroll
+                    for (int j = 0; j < 2; j++) ct_bfly(x[2 * k + j], x[2 * (k + d) + j], w.x, w.y, nq, q4);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                u64x2 v;
+                v.x = x[2 * k];
+                v.y = x[2 * k + 1];
+                *reinterpret_cast<u64x2 *>(&lds[phi(2 * tau + NB * k)]) = v;
+            }
+            __syncthreads();
+            // ---- pass B: 16 << sb local groups; columns rho + SB k of block beta ---------------------
+#pragma unroll
+            for (int k = 0; k < 32; k++) x[k] = lds[phi(NB * beta + rho + SB * k)];
+#pragma unroll
+            for (int sb = 0; sb < 5; sb++) {
+                const int d = 16 >> sb;
+#pragma unroll
+                for (int k = 0; k < 32; k++) {
+                    if (k & d) continue;
+                    const u32 ml = 16u << sb, i = (beta << sb) + ((u32)k >> (5 - sb));
+                    const u64x2 w = tw[(ml << a.s0) + blk * ml + i];
+                    ct_bfly(x[k], x[k + d], w.x, w.y, nq, q4);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 32; k++) lds[phi(NB * beta + rho + SB * k)] = x[k];
+            __syncthreads();
+            // ---- pass C: 512 << sc local groups; 32 contiguous coefficients ---------------------------
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const u64x2 v = *reinterpret_cast<const u64x2 *>(&lds[phi(32 * tau + 2 * k)]);
+                x[2 * k] = v.x;
+                x[2 * k + 1] = v.y;
+            }
+#pragma unroll
+            for (int sc = 0; sc < C; sc++) {
+                const int d = 1 << (C - 1 - sc);
+#pragma unroll
+                for (int k = 0; k < 32; k++) {
+                    if (k & d) continue;
+                    const u32 ml = 512u << sc, i = (tau << (5 - C + sc)) + ((u32)k >> (C - sc));
+                    const u64x2 w = tw[(ml << a.s0) + blk * ml + i];
+                    ct_bfly(x[k], x[k + d], w.x, w.y, nq, q4);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                u64x2 v;
+                u64 r0 = x[2 * k], r1 = x[2 * k + 1];
+                r0 = r0 >= q4 ? r0 - q4 : r0;
+                r1 = r1 >= q4 ? r1 - q4 : r1;
+                r0 = r0 >= q2 ? r0 - q2 : r0;
+                r1 = r1 >= q2 ? r1 - q2 : r1;
+                v.x = r0 >= q ? r0 - q : r0;
+                v.y = r1 >= q ? r1 - q : r1;
+                *reinterpret_cast<u64x2 *>(&lds[phi(32 * tau + 2 * k)]) = v;
+            }
+            __syncthreads();
+            // ---- coalesced copy-out -------------------------------------------------------------------
+#ifndef NTT_EXP_NOSTORE
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                *reinterpret_cast<u64x2 *>(g + 2 * tau + NB * k) = *reinterpret_cast<const u64x2 *>(&lds[phi(2 * tau + NB * k)]);
+#else
+            if (tau == 1000) g[0] = lds[phi(tau)];
+#endif
+            __syncthreads();
+        } else {
+            // ---- copy-in through LDS to reach the 32-contiguous layout ------------------------------------
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                u64x2 v;
+                v.x = x[2 * k];
+                v.y = x[2 * k + 1];
+                *reinterpret_cast<u64x2 *>(&lds[phi(2 * tau + NB * k)]) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const u64x2 v = *reinterpret_cast<const u64x2 *>(&lds[phi(32 * tau + 2 * k)]);
+                x[2 * k] = v.x;
+                x[2 * k + 1] = v.y;
+            }
+            // ---- pass C': distances 1, 2, .. 2^(C-1) -----------------------------------------------------------
+#pragma unroll
+            for (int sc = C - 1; sc >= 0; sc--) {
+                const int d = 1 << (C - 1 - sc);
+#pragma unroll
+                for (int k = 0; k < 32; k++) {
+                    if (k & d) continue;
+                    const u32 ml = 512u << sc, i = (tau << (5 - C + sc)) + ((u32)k >> (C - sc));
+                    const u64x2 w = tw[(ml << a.s0) + blk * ml + i];
+                    gs_bfly(x[k], x[k + d], w.x, w.y, nq, q4);
+                    BFLY_FENCE(k, FENCE_EVERY);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                u64x2 v;
+                v.x = x[2 * k];
+                v.y = x[2 * k + 1];
+                *reinterpret_cast<u64x2 *>(&lds[phi(32 * tau + 2 * k)]) = v;
+            }
+            __syncthreads();
+            // ---- pass B' -----------------------------------------------------------------------------------------
+#pragma unroll
+            for (int k = 0; k < 32; k++) x[k] = lds[phi(NB * beta + rho + SB * k)];
+#pragma unroll
+            for (int sb = 4; sb >= 0; sb--) {
+                const int d = 16 >> sb;
+#pragma unroll
+                for (int k = 0; k < 32; k++) {
+                    if (k & d) continue;
+                    const u32 ml = 16u << sb, i = (beta << sb) + ((u32)k >> (5 - sb));
+                    const u64x2 w = tw[(ml << a.s0) + blk * ml + i];
+                    gs_bfly(x[k], x[k + d], w.x, w.y, nq, q4);
+                    BFLY_FENCE(k, FENCE_EVERY);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 32; k++) lds[phi(NB * beta + rho + SB * k)] = x[k];
+            __syncthreads();
+            // ---- pass A' + scaling, stored straight to HBM -------------------------------------------------------
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const u64x2 v = *reinterpret_cast<const u64x2 *>(&lds[phi(2 * tau + NB * k)]);
+                x[2 * k] = v.x;
+                x[2 * k + 1] = v.y;
+            }
+            __syncthreads();  // the next slice's copy-in overwrites the image
+            if (next < a.nitems) {  // prefetch: latency hides behind pass A' (scalar twiddles, low pressure)
+                const u64 *gn = gdata + (size_t)next * n;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const u64x2 v = *reinterpret_cast<const u64x2 *>(gn + 2 * tau + NB * k);
+                    y[2 * k] = v.x;
+                    y[2 * k + 1] = v.y;
+                }
+            }
+#pragma unroll
+            for (int s = 3; s >= 0; s--) {
+                const int d = 8 >> s;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (k & d) continue;
+                    const u32 ml = 1u << s, i = (u32)k >> (4 - s);
+                    const u64x2 w = tw[(ml << a.s0) + blk * ml + i];
+#pragma unroll
+                    for (int j = 0; j < 2; j++) gs_bfly(x[2 * k + j], x[2 * (k + d) + j], w.x, w.y, nq, q4);
+                    BFLY_FENCE(k, FENCE_EVERY / 2);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                u64x2 v;
+                if (a.s0 == 0) {
+                    v.x = mul_shoup(x[2 * k], m.n_inv, m.n_inv_sh, q);
+                    v.y = mul_shoup(x[2 * k + 1], m.n_inv, m.n_inv_sh, q);
+                } else {
+                    u64 r0 = x[2 * k], r1 = x[2 * k + 1];
+                    r0 = r0 >= q2 ? r0 - q2 : r0;
+                    r1 = r1 >= q2 ? r1 - q2 : r1;
+                    v.x = r0 >= q ? r0 - q : r0;
+                    v.y = r1 >= q ? r1 - q : r1;
+                }
+                *reinterpret_cast<u64x2 *>(g + 2 * tau + NB * k) = v;
+            }
+        }
+    }
+}
+
+template <int LOGN, bool INV>
+static void launch_one(const NttFastArgs &a, u32 max_groups, hipStream_t st)
+{
+    constexpr u32 n = 1u << LOGN;
+    constexpr size_t lds = (size_t)(n + n / 16) * sizeof(u64);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)ntt_fast_kernel<LOGN, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    u32 grid = a.nitems < max_groups ? a.nitems : max_groups;
+    hipLaunchKernelGGL((ntt_fast_kernel<LOGN, INV>), dim3(grid), dim3(n / 32), lds, st, a.data, reinterpret_cast<const u64x2 *>(a.twp), a.dc, a);
+}
+
+// returns false if this slice size has no register-blocked kernel
+bool launch_ntt_fast(const u64 *twp, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
+                     u32 mod_count, bool inverse, u32 num_cus, hipStream_t st)
+{
+    const u32 logn = logN - s0;
+    if (logn < 12 || logn > 14) return false;
+    NttFastArgs a;
+    a.data = data;
+    a.twp = twp;
+    a.dc = dc;
+    a.N = N;
+    a.logN = logN;
+    a.s0 = s0;
+    a.nitems = nlimbs << s0;
+    a.mod_base = mod_base;
+    a.mod_count = mod_count;
+    // resident workgroups per CU by LDS: 136 KiB -> 1, 68 KiB -> 2, 34 KiB -> 4
+    const u32 per_cu = logn == 14 ? 1 : (logn == 13 ? 2 : 4);
+    const u32 maxg = num_cus * per_cu;
+    if (logn == 14) {
+        if (inverse) launch_one<14, true>(a, maxg, st); else launch_one<14, false>(a, maxg, st);
+    } else if (logn == 13) {
+        if (inverse) launch_one<13, true>(a, maxg, st); else launch_one<13, false>(a, maxg, st);
+    } else {
+        if (inverse) launch_one<12, true>(a, maxg, st); else launch_one<12, false>(a, maxg, st);
+    }
+    return true;
+}
+
+}  // namespace piehip

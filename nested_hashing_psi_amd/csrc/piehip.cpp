@@ -59,6 +59,7 @@ struct piehip_ctx {
     bool own_stream = false;
     DevConsts *d_dc = nullptr;
     u64 *d_tables = nullptr;  // [(M+1)][4][N]
+    u64 *d_twp = nullptr;     // [(M+1)][2][N][2] interleaved {w, w_shoup}
     u32 *d_inv_pos = nullptr; // EVALUATION position -> slot
     NttPlan plan;
     // keys / database / inputs
@@ -280,6 +281,20 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
         CHK_(hipMemcpy(base + 3 * (size_t)N, h->hp.itw_sh[a].data(), sizeof(u64) * N, hipMemcpyHostToDevice));
     }
     {
+        std::vector<u64> pairs((size_t)(M + 1) * 4 * N);
+        for (u32 a = 0; a <= M; a++)
+            for (u32 k = 0; k < N; k++) {
+                u64 *f = &pairs[((size_t)a * 2 + 0) * 2 * N + 2 * (size_t)k];
+                u64 *i = &pairs[((size_t)a * 2 + 1) * 2 * N + 2 * (size_t)k];
+                f[0] = h->hp.tw[a][k];
+                f[1] = h->hp.tw_sh[a][k];
+                i[0] = h->hp.itw[a][k];
+                i[1] = h->hp.itw_sh[a][k];
+            }
+        CHK_(hipMalloc((void **)&h->d_twp, pairs.size() * sizeof(u64)));
+        CHK_(hipMemcpy(h->d_twp, pairs.data(), pairs.size() * sizeof(u64), hipMemcpyHostToDevice));
+    }
+    {
         std::vector<u32> inv(N, 0xFFFFFFFFu);
         for (u32 s = 0; s < N; s++) inv[h->hp.slot_pos[s]] = s;
         CHK_(hipMalloc((void **)&h->d_inv_pos, sizeof(u32) * N));
@@ -287,6 +302,13 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
     }
 #undef CHK_
     h->plan.tables = h->d_tables;
+    h->plan.twp = h->d_twp;
+    h->plan.force_generic = false;
+    {
+        hipDeviceProp_t prop;
+        h->plan.num_cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+                              ? (u32)prop.multiProcessorCount : 256u;
+    }
     h->plan.dc = h->d_dc;
     h->plan.N = N;
     h->plan.logN = h->hp.logN;
@@ -311,6 +333,7 @@ int piehip_destroy(piehip_handle h)
     ws_free(h->ws);
     if (h->d_dc) (void)hipFree(h->d_dc);
     if (h->d_tables) (void)hipFree(h->d_tables);
+    if (h->d_twp) (void)hipFree(h->d_twp);
     if (h->d_inv_pos) (void)hipFree(h->d_inv_pos);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -734,6 +757,42 @@ int piehip_base_convert(piehip_handle h, int which, const uint64_t *in, uint32_t
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, dout, wout * sizeof(u64), hipMemcpyDeviceToHost));
+    return PIEHIP_OK;
+}
+
+int piehip_bench_ntt(piehip_handle h, uint32_t nlimbs, uint32_t mod_count, int inverse, uint32_t iters, double *ms_per_launch)
+{
+    NEED(h);
+    if (!nlimbs || !mod_count || mod_count > h->hp.M || !iters || !ms_per_launch) return fail(PIEHIP_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    Tmp tmp;
+    const u32 N = h->hp.N;
+    const size_t words = (size_t)nlimbs * N;
+    TMPGET(d, words);
+    {   // residues below the smallest modulus are valid for every limb
+        std::vector<u64> host(words);
+        u64 lo = h->hp.moduli[0];
+        for (u32 a = 1; a < mod_count; a++) lo = h->hp.moduli[a] < lo ? h->hp.moduli[a] : lo;
+        u64 s = 0x9E3779B97F4A7C15ULL;
+        for (size_t i = 0; i < words; i++) {
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            host[i] = s % lo;
+        }
+        HIPCHK(hipMemcpy(d, host.data(), words * sizeof(u64), hipMemcpyHostToDevice));
+    }
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    launch_ntt(h->plan, d, nlimbs, 0, mod_count, inverse != 0, h->stream);  // warm-up
+    HIPCHK(hipEventRecord(e0, h->stream));
+    for (u32 i = 0; i < iters; i++) launch_ntt(h->plan, d, nlimbs, 0, mod_count, inverse != 0, h->stream);
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = (double)ms / iters;
     return PIEHIP_OK;
 }
 

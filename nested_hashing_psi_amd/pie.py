@@ -146,6 +146,11 @@ class PieContext:
         _check(lib().piehip_load_relin_key(self._h, ap))
 
     # -- measurement
+    def bench_ntt(self, nlimbs, mod_count=None, inverse=False, iters=20):
+        ms = C.c_double()
+        _check(lib().piehip_bench_ntt(self._h, nlimbs, mod_count or self.M, int(inverse), iters, C.byref(ms)))
+        return ms.value
+
     def set_profiling(self, on):
         _check(lib().piehip_set_profiling(self._h, int(on)))
 

@@ -8,6 +8,35 @@ typedef uint32_t u32;
 #define ITER 4096
 #define CH 8
 
+__device__ __forceinline__ u64 mad_u(u32 a, u32 b, u64 c)
+{
+    u64 d, sc;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(sc) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ u64 mul_u(u32 a, u32 b)
+{
+    u64 d, sc;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(sc) : "v"(a), "v"(b));
+    return d;
+}
+// Shoup multiply, quotient estimate from 3 partial products: result in [0, 4q)
+__device__ __forceinline__ u64 shoup4(u64 b, u64 w, u64 ws, u64 nq)
+{
+    const u32 bl = (u32)b, bh = (u32)(b >> 32), wl = (u32)w, wh = (u32)(w >> 32), sl = (u32)ws, sh = (u32)(ws >> 32);
+    const u32 nql = (u32)nq, nqh = (u32)(nq >> 32);
+    const u64 m1 = mul_u(bl, sh);
+    const u64 m2 = mad_u(bh, sl, m1 >> 32);
+    const u64 qe = mad_u(bh, sh, m2 >> 32);
+    u64 acc = mul_u((u32)qe, nql);
+    acc = mad_u(bl, wl, acc);
+    u64 c = mul_u((u32)qe, nqh);
+    c = mad_u((u32)(qe >> 32), nql, c);
+    c = mad_u(bl, wh, c);
+    c = mad_u(bh, wl, c);
+    return acc + ((u64)(u32)c << 32);
+}
+
 template <int OP>
 __global__ void __launch_bounds__(256) probe(u64 *out, u64 seed, u64 q, u64 w, u64 wsh)
 {
@@ -37,6 +66,27 @@ __global__ void __launch_bounds__(256) probe(u64 *out, u64 seed, u64 q, u64 w, u
                     u64 t = v * w - __umul64hi(v, wsh) * q;
                     x[c - 1] = u + t;
                     x[c] = u - t + 2 * q;
+                }
+            } else if (OP == 12) {  // asm Shoup [0,4q)
+                x[c] = shoup4(x[c], w, wsh, 0 - q);
+            } else if (OP == 13) {  // asm butterfly, [0,8q) invariant
+                if (c & 1) {
+                    u64 u = x[c - 1], v = x[c];
+                    const u64 q4 = 4 * q;
+                    u = u >= q4 ? u - q4 : u;
+                    u64 t = shoup4(v, w, wsh, 0 - q);
+                    x[c - 1] = u + t;
+                    x[c] = u - t + q4;
+                }
+            } else if (OP == 14) {  // asm butterfly, sign-select conditional subtract
+                if (c & 1) {
+                    u64 u = x[c - 1], v = x[c];
+                    const u64 q4 = 4 * q;
+                    const u64 tt = u - q4;
+                    u = (long long)tt < 0 ? u : tt;
+                    u64 t = shoup4(v, w, wsh, 0 - q);
+                    x[c - 1] = u + t;
+                    x[c] = u - t + q4;
                 }
             } else if (OP == 7) {  // 64-bit add
                 x[c] = x[c] + w + (x[c] >> 7);
@@ -104,6 +154,9 @@ int main()
     run<5>("shoup_lazy modmul", 1, d);
     run<6>("harvey butterfly", 0.5, d);
     run<11>("solinas modmul", 1, d);
+    run<12>("asm shoup4 (9 mad)", 1, d);
+    run<13>("asm butterfly 8q", 0.5, d);
+    run<14>("asm butterfly 8q signsel", 0.5, d);
     run<7>("add64 x2 + shift", 1, d);
     run<8>("fma_f64", 1, d);
     hipFree(d);
