@@ -78,6 +78,19 @@ def cpu_baseline(cfg, seconds_target=12.0):
                       "CPU restatement in C (oracle/), OpenFHE not available" % (done, cfg["name"], K, E, K * E, dt)}
 
 
+def pmc_traffic(config):
+    """HBM bytes per NTT launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/latest_pmc.json, written by tools/pmc_summary.py; FETCH_SIZE x2 + WRITE_SIZE, gfx950
+    corrections of MI355X_MICROARCH.md).  None if no profile of this config is committed."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+        if d.get("config") == config:
+            return d["ntt"]["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,7 +103,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from nested_hashing_psi_amd import pie
+    from nested_hashing_psi_amd import pie, shard
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -113,8 +126,7 @@ def main():
     N, L, t, K, E, b = cfg["N"], cfg["L"], cfg["t"], cfg["K"], cfg["E"], cfg["b"]
     B = cfg["k"] * cfg["e"]
     if args.scaling == "strong" and world > 1:
-        lo = (b * rank) // world
-        hi = (b * (rank + 1)) // world
+        lo, hi = shard.bin_slice(b, rank, world)
         b_local = hi - lo
     else:
         b_local = b
@@ -141,23 +153,20 @@ def main():
         op.setMinusCompareElementDevice(minus.data_ptr())
     ct_words = 2 * L * N
     gathered = None
-    my_out = torch.zeros((max(b_local, 1), ct_words), dtype=torch.int64, device=device)
+    my_out = None
     if world > 1:
-        bmax = -(-b // world) if args.scaling == "strong" else b_local
+        # gather buffers allocated once, outside the timed region
+        bmax = shard.max_bins(b, world) if args.scaling == "strong" else b_local
         my_out = torch.zeros((bmax, ct_words), dtype=torch.int64, device=device)
         gathered = torch.empty((world * bmax, ct_words), dtype=torch.int64, device=device)
-
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
 
     def step():
         if op is not None:
             op.run(sync=False)
         if world > 1:
             if op is not None:
-                # results -> the gather buffer (device-to-device on the same stream), then RCCL all-gather
-                hip.hipMemcpyAsync(ctypes.c_void_p(my_out.data_ptr()), ctypes.c_void_p(op.resultsDevicePtr()),
-                                   ctypes.c_size_t(b_local * ct_words * 8), 3, ctypes.c_void_p(stream.cuda_stream))
+                op.copyResultsToDevice(my_out.data_ptr())   # same stream as run(): ordered after it
+            # the path's only collective: RCCL all-gather of the result ciphertexts
             dist.all_gather_into_tensor(gathered, my_out)
 
     for _ in range(args.warmup):
@@ -202,7 +211,7 @@ def main():
         if ntt_ms > 0:
             ach = ntt_bytes / (ntt_ms * 1e-3) / 1e9
             roofline = {"kernel": "ntt (forward+inverse, LDS-resident limb)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config),
                         "avg_launch_us": 1e3 * ntt_ms / ntt_launch, "alg_bytes_per_launch": ntt_bytes / ntt_launch,
                         "launches_per_step": ntt_launch / args.profile_steps}
 

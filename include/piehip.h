@@ -93,6 +93,8 @@ int piehip_sync(piehip_handle h);
 int piehip_get_results(piehip_handle h, uint64_t *out);
 /* device address of the result buffer [b][2][L][N] (valid until destroy); for the RCCL gather */
 int piehip_results_device(piehip_handle h, void **d_out);
+/* enqueue a device-to-device copy of the results into caller-owned HBM (e.g. the RCCL gather buffer) */
+int piehip_copy_results_device(piehip_handle h, void *d_dst);
 
 /* ---- the OpenFHE primitives under run(), exposed one by one for kernel-level parity tests ------
  * (host buffers in, host buffers out; synchronous) */

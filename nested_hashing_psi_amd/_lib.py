@@ -35,6 +35,7 @@ SYMBOLS = {
     "piehip_sync": (C.c_int, [C.c_void_p]),
     "piehip_get_results": (C.c_int, [C.c_void_p, u64p]),
     "piehip_results_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "piehip_copy_results_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "piehip_ntt": (C.c_int, [C.c_void_p, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     "piehip_eval_add": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "piehip_eval_mult_plain": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),

@@ -575,6 +575,15 @@ int piehip_results_device(piehip_handle h, void **d_out)
     return PIEHIP_OK;
 }
 
+int piehip_copy_results_device(piehip_handle h, void *d_dst)
+{
+    NEED(h);
+    if (!d_dst) return fail(PIEHIP_EINVAL, "null destination");
+    if (!h->d_out) return fail(PIEHIP_ESTATE, "no results");
+    HIPCHK(hipMemcpyAsync(d_dst, h->d_out, sizeof(u64) * (size_t)h->b * 2 * h->LN(), hipMemcpyDeviceToDevice, h->stream));
+    return PIEHIP_OK;
+}
+
 // ---- kernel-level entry points (tests) -------------------------------------------------------------
 namespace {
 struct Tmp {  // RAII device scratch for the synchronous test entry points

@@ -1,0 +1,185 @@
+// BatchedFHEHIPPIE.hpp -- C++ host facade over the C ABI (include/piehip.h).
+//
+// Same class shape as the reference operator
+//     src/Common/Crypto/PrivateIndexedEqualityCheck/BatchedFHEHIPPIE.hpp:18-49
+// (constructor, run(), getResultList(), setIndex(&&), setMinusCompareElement()), the same call order
+// the server uses (src/Server/FHE/BatchedFHEPSIServer.cpp:86,101-103,108) and the same error behaviour
+// (std::invalid_argument for a stash or combined tables, BatchedFHEHIPPIE.cpp:13-21; std::runtime_error
+// for everything the library reports at run time).
+//
+// The reference class is written against lbcrypto::Ciphertext<DCRTPoly> / lbcrypto::Plaintext.  OpenFHE is
+// not available to this build, so the facade is a template over a small "limb traits" adapter: anything that
+// can copy its RNS towers (EVALUATION format, uint64_t[N] each) into and out of a flat buffer.  piehip::LimbCt /
+// piehip::LimbPt below are the plain-memory instances the tests use; INTEGRATION.md gives the OpenFHE instance
+// (DCRTPoly::GetElementAtIndex(i).GetValues() <-> limb arrays), which is the only code a maintainer adds.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/piehip.h"
+
+namespace piehip {
+
+// flat limb containers: the layout of a DCRTPoly's towers
+struct LimbPt {                       // plaintext: [L][N]
+    std::vector<uint64_t> limbs;
+};
+struct LimbCt {                       // ciphertext: [2][L][N]
+    std::vector<uint64_t> limbs;
+};
+
+// What the reference reads from its HierarchicalCuckooHashTable in the constructor
+// (BatchedFHEHIPPIE.cpp:13-21,37-41,48-66): sizes, the two argument checks, and the raw table
+// tbl[k][e][K][b][E] (outer hash fn, outer position, inner hash fn, bin layer, inner position).
+struct HashTableView {
+    uint32_t numberOfSimpleTables = 0;      // k
+    uint32_t eachSimpleTableSize = 0;       // e
+    uint32_t numberOfCuckooTables = 0;      // K
+    uint32_t eachBinSize = 0;               // b
+    uint32_t eachCuckooTableSize = 0;       // E
+    uint64_t serverStashSize = 0;
+    bool simpleMultiTables = true, cuckooMultiTables = true;
+    const uint64_t *table = nullptr;        // [k][e][K][b][E]
+};
+
+// Owner of the device context: the role lbcrypto::CryptoContext<DCRTPoly> plays for the reference
+// (BatchedFHEPSIServer.hpp:21; created from the client's serialized context at .cpp:21-54).
+class PieContext {
+public:
+    PieContext(uint32_t N, uint32_t L, uint64_t t, const uint64_t *q = nullptr, const uint64_t *p = nullptr, int device = 0,
+               void *stream = nullptr)
+        : N_(N), L_(L), t_(t)
+    {
+        check(piehip_create(&h_, N, L, t, q, p, device, stream));
+    }
+    ~PieContext() { piehip_destroy(h_); }
+    PieContext(const PieContext &) = delete;
+    PieContext &operator=(const PieContext &) = delete;
+
+    // InsertEvalMultKey / DeserializeEvalMultKey (BatchedFHEPSIServer.cpp:49): evk[L][2][L][N]
+    void setEvalMultKey(const uint64_t *evk) { check(piehip_load_relin_key(h_, evk)); }
+    uint64_t GetPlaintextModulus() const { return t_; }
+    uint32_t ringDimension() const { return N_; }
+    uint32_t towers() const { return L_; }
+    piehip_handle handle() const { return h_; }
+
+    static void check(int rc)
+    {
+        if (rc == PIEHIP_OK) return;
+        const std::string msg = piehip_last_error();
+        if (rc == PIEHIP_EINVAL) throw std::invalid_argument(msg);
+        throw std::runtime_error(msg);
+    }
+
+private:
+    piehip_handle h_ = nullptr;
+    uint32_t N_, L_;
+    uint64_t t_;
+};
+
+class BatchedFHEHIPPIE {
+public:
+    // BatchedFHEHIPPIE(cryptoContext, pK, hct), BatchedFHEHIPPIE.cpp:9-86.  The public key is unused by the
+    // reference constructor and run() (it is only stored, .hpp:22), so it does not appear here.  The bin-layer
+    // shuffle (.cpp:23-35) and the random masks (.cpp:72-82) take explicit seeds instead of std::random_device.
+    BatchedFHEHIPPIE(PieContext &cryptoContext, const HashTableView &hct, uint64_t shuffleSeed = 0x9E3779B97F4A7C15ULL,
+                     uint64_t maskSeed = 0xD1B54A32D192ED03ULL)
+        : cc(cryptoContext)
+    {
+        if (hct.serverStashSize != 0) throw std::invalid_argument("Error, batched FHE PIE does not support a stash (yet).");
+        if (!hct.simpleMultiTables || !hct.cuckooMultiTables)
+            throw std::invalid_argument("Error, batched FHE PIE currently does not support combined tables.");
+        K = hct.numberOfCuckooTables;
+        b = hct.eachBinSize;
+        E = hct.eachCuckooTableSize;
+        const uint32_t k = hct.numberOfSimpleTables, e = hct.eachSimpleTableSize;
+        const size_t B = (size_t)k * e;  // batch size, .cpp:41 (assumes simple multi table)
+        if (B > cc.ringDimension()) throw std::invalid_argument("batch size exceeds the ring dimension");
+        const uint64_t t = cc.GetPlaintextModulus();
+
+        // shuffle the bin layers of every (sub-table, inner hash function) row, .cpp:28-35
+        std::vector<uint32_t> perm((size_t)k * e * K * b);
+        uint64_t s = shuffleSeed;
+        for (size_t row = 0; row < (size_t)k * e * K; row++) {
+            uint32_t *p = &perm[row * b];
+            for (uint32_t i = 0; i < b; i++) p[i] = i;
+            for (uint32_t i = b - 1; i > 0; i--) std::swap(p[i], p[next(s) % (i + 1)]);
+        }
+        // gather DB[h][bin][j][slot] = table[slot/e][slot%e].cuckooTable[h][perm(bin)][j], .cpp:48-66
+        std::vector<int64_t> slots((size_t)K * b * E * B);
+        for (uint32_t h = 0; h < K; h++)
+            for (uint32_t bin = 0; bin < b; bin++)
+                for (uint32_t j = 0; j < E; j++) {
+                    int64_t *dst = &slots[(((size_t)h * b + bin) * E + j) * B];
+                    for (size_t sl = 0; sl < B; sl++) {
+                        const uint32_t src_bin = perm[(sl * K + h) * b + bin];
+                        const uint64_t v = hct.table[((sl * K + h) * b + src_bin) * E + j];
+                        if (v >= t) throw std::invalid_argument("table item does not fit the plaintext modulus");
+                        dst[sl] = v > t / 2 ? (int64_t)v - (int64_t)t : (int64_t)v;
+                    }
+                }
+        // masks uniform in [1, t-1], .cpp:73-82
+        std::vector<int64_t> masks((size_t)b * B);
+        s = maskSeed;
+        for (auto &m : masks) {
+            const uint64_t v = next(s) % (t - 1) + 1;
+            m = v > t / 2 ? (int64_t)v - (int64_t)t : (int64_t)v;
+        }
+        // MakePackedPlaintext of all K*b*E + b vectors on the device, .cpp:68,81
+        PieContext::check(piehip_load_db_slots(cc.handle(), K, b, E, (uint32_t)B, slots.data(), masks.data()));
+        resultList.resize(b);
+    }
+
+    void run()  // BatchedFHEHIPPIE.cpp:88-129
+    {
+        PieContext::check(piehip_run(cc.handle()));
+        const size_t ct = 2 * (size_t)cc.towers() * cc.ringDimension();
+        std::vector<uint64_t> flat(ct * b);
+        PieContext::check(piehip_get_results(cc.handle(), flat.data()));
+        for (uint32_t i = 0; i < b; i++) resultList[i].limbs.assign(flat.begin() + i * ct, flat.begin() + (i + 1) * ct);
+    }
+
+    std::vector<LimbCt> &getResultList() { return resultList; }  // .hpp:35-38
+
+    void setIndex(std::vector<std::vector<LimbCt>> &&indexMatrix)  // .hpp:40-43, [K][E] ciphertexts
+    {
+        const size_t ct = 2 * (size_t)cc.towers() * cc.ringDimension();
+        if (indexMatrix.size() != K) throw std::invalid_argument("index matrix must have one row per inner hash function");
+        std::vector<uint64_t> flat((size_t)K * E * ct);
+        for (uint32_t h = 0; h < K; h++) {
+            if (indexMatrix[h].size() != E) throw std::invalid_argument("index matrix row length must be eachCuckooTableSize");
+            for (uint32_t j = 0; j < E; j++) {
+                if (indexMatrix[h][j].limbs.size() != ct) throw std::invalid_argument("ciphertext does not match the context");
+                std::memcpy(&flat[((size_t)h * E + j) * ct], indexMatrix[h][j].limbs.data(), ct * sizeof(uint64_t));
+            }
+        }
+        PieContext::check(piehip_set_index(cc.handle(), flat.data()));
+    }
+
+    void setMinusCompareElement(LimbCt minusCompareElement)  // .hpp:45-48
+    {
+        if (minusCompareElement.limbs.size() != 2 * (size_t)cc.towers() * cc.ringDimension())
+            throw std::invalid_argument("ciphertext does not match the context");
+        PieContext::check(piehip_set_minus(cc.handle(), minusCompareElement.limbs.data()));
+    }
+
+protected:
+    PieContext &cc;
+    uint32_t K = 0, b = 0, E = 0;
+    std::vector<LimbCt> resultList;
+
+    static uint64_t next(uint64_t &s)  // splitmix64
+    {
+        s += 0x9E3779B97F4A7C15ULL;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        return z ^ (z >> 31);
+    }
+};
+
+}  // namespace piehip

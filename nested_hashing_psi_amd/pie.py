@@ -230,6 +230,9 @@ class BatchedFHEHIPPIE:
         _check(lib().piehip_get_results(self.cc._h, out.ctypes.data_as(u64p)))
         return out
 
+    def copyResultsToDevice(self, ptr):
+        _check(lib().piehip_copy_results_device(self.cc._h, ptr))
+
     def resultsDevicePtr(self):
         p = C.c_void_p()
         _check(lib().piehip_results_device(self.cc._h, C.byref(p)))

@@ -1,0 +1,47 @@
+// Compile-and-link check of the C++ host facade against libpiehip.so (run by tests/test_abi.py).
+// With a GPU it also runs the reference's call order on a tiny table; without one it verifies that
+// construction fails loudly (no CPU fallback).
+#include <cstdio>
+#include <vector>
+
+#include "../nested_hashing_psi_amd/host/BatchedFHEHIPPIE.hpp"
+
+int main()
+{
+    using namespace piehip;
+    // argument checks of the reference constructor need no device
+    HashTableView v;
+    v.numberOfSimpleTables = 2, v.eachSimpleTableSize = 2, v.numberOfCuckooTables = 2, v.eachBinSize = 2, v.eachCuckooTableSize = 3;
+    std::vector<uint64_t> tbl(2 * 2 * 2 * 2 * 3, 0);
+    for (size_t i = 0; i < tbl.size(); i++) tbl[i] = (i * 7919u) % 65536u + 1;
+    v.table = tbl.data();
+    try {
+        PieContext cc(1024, 2, 65537);
+        bool threw = false;
+        try {
+            HashTableView bad = v;
+            bad.serverStashSize = 1;
+            BatchedFHEHIPPIE pie(cc, bad);
+        } catch (const std::invalid_argument &) {
+            threw = true;
+        }
+        if (!threw) return 2;
+        BatchedFHEHIPPIE pie(cc, v);
+        const size_t ct = 2 * 2 * 1024;
+        std::vector<uint64_t> evk(2 * 2 * 2 * 1024, 1);
+        cc.setEvalMultKey(evk.data());
+        LimbCt minus;
+        minus.limbs.assign(ct, 3);
+        std::vector<std::vector<LimbCt>> idx(2, std::vector<LimbCt>(3));
+        for (auto &row : idx)
+            for (auto &c : row) c.limbs.assign(ct, 5);
+        pie.setMinusCompareElement(minus);
+        pie.setIndex(std::move(idx));
+        pie.run();
+        std::printf("facade ok: %zu result ciphertexts\n", pie.getResultList().size());
+        return 0;
+    } catch (const std::runtime_error &e) {
+        std::printf("no device: %s\n", e.what());
+        return 77;  // skipped: no GPU
+    }
+}

@@ -59,3 +59,16 @@ def test_product_does_not_touch_the_oracle():
                     code = line.split("//")[0].split("#")[0] if not f.endswith(".py") else line.split("#")[0]
                     assert "pie_oracle" not in code and "libpieoracle" not in code and "from oracle" not in code \
                         and "import oracle" not in code, "%s references the oracle: %s" % (f, line)
+
+
+def test_cpp_facade_compiles_and_links(built, tmp_path):
+    """nested_hashing_psi_amd/host/BatchedFHEHIPPIE.hpp (the reference class shape over the C ABI) builds
+    with g++ against libpiehip.so; without a GPU it must fail loudly at context creation (rc 77)."""
+    import subprocess
+    exe = str(tmp_path / "facade_check")
+    libdir = os.path.dirname(built)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "facade_check.cpp"),
+                           "-L" + libdir, "-lpiehip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    rc = subprocess.call([exe])
+    import torch
+    assert rc == (0 if torch.cuda.is_available() else 77)

@@ -227,3 +227,15 @@ def test_error_behaviour(ob, pie):
     with pytest.raises(ValueError):
         pie.PieContext(1024, 2, 65539)  # t not 1 mod 2N / not prime
     cc.close()
+
+
+def test_cpp_facade_runs_reference_call_order(tmp_path):
+    """the C++ facade (reference class shape) drives setMinusCompareElement / setIndex / run / getResultList"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "nested_hashing_psi_amd")
+    exe = str(tmp_path / "facade_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(root, "tests", "facade_check.cpp"),
+                           "-L" + libdir, "-lpiehip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    assert subprocess.call([exe]) == 0

@@ -1,0 +1,79 @@
+"""N > 1 path on CPU: two `gloo` ranks each evaluate their slice of bin layers (with the oracle standing
+in for the GPU) and gather; the result must equal the unsharded run bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, b, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nested_hashing_psi_amd import shard
+        from oracle import binding as ob
+        N, L, t, K, E = 1024, 2, 65537, 2, 3
+        o = ob.Oracle(N, L, t)
+        rng = np.random.default_rng(42)  # same inputs on every rank
+
+        def rl(shape):
+            out = np.zeros(shape + (L, N), dtype=np.uint64)
+            for i in range(L):
+                out[..., i, :] = rng.integers(0, int(o.q[i]), shape + (N,), dtype=np.uint64)
+            return out
+
+        idx, minus, db, masks, evk = rl((K, E, 2)), rl((2,)), rl((K, b, E)), rl((b,)), rl((L, 2))
+        lo, hi = shard.bin_slice(b, rank, world)
+        # this rank holds only its slice of the database (as a GPU rank would)
+        local = o.pie_run(idx, minus, np.ascontiguousarray(db[:, lo:hi]), np.ascontiguousarray(masks[lo:hi]), evk)
+        local_t = torch.from_numpy(local.reshape(hi - lo, 2 * L * N).view(np.int64))
+        full = shard.gather_bins(local_t, b, world)
+        want = o.pie_run(idx, minus, db, masks, evk).reshape(b, 2 * L * N).view(np.int64)
+        ok = bool((full.numpy() == want).all()) and full.shape[0] == b
+        q.put((rank, ok, (lo, hi)))
+    except Exception as e:  # report instead of hanging the parent on q.get
+        q.put((rank, False, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("b", [4, 5, 1])
+def test_two_rank_gather_matches_unsharded(b):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, b, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    slices = sorted(s for _, _, s in res)
+    assert slices[0][0] == 0 and slices[-1][1] == b and slices[0][1] == slices[1][0]
+
+
+def test_bin_slices_partition():
+    from nested_hashing_psi_amd import shard
+    for b in (1, 7, 14, 30, 40):
+        for world in (1, 2, 4, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = shard.bin_slice(b, r, world)
+                cover += list(range(lo, hi))
+                assert hi - lo <= shard.max_bins(b, world)
+            assert cover == list(range(b))
