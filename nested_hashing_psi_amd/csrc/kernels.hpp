@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include "params.hpp"
 
 namespace piehip {
@@ -11,6 +13,7 @@ namespace piehip {
 struct NttPlan {
     const u64 *tables;
     const u64 *twp;       // interleaved {w, w_shoup} pairs: per modulus [fwd N pairs][inv N pairs]
+    const u64 *twc;       // pass-C twiddles in kernel order: per modulus [fwd][inv], see build_twc_table
     const DevConsts *dc;  // device pointer
     u32 N, logN;
     u32 num_cus;
@@ -19,7 +22,9 @@ struct NttPlan {
 
 // In-place negacyclic NTT over `nlimbs` limbs [nlimbs][N]; limb i uses modulus mod_base + i % mod_count.
 // (replaces DCRTPoly::SetFormat under BatchedFHEHIPPIE.cpp:123)
-bool launch_ntt_fast(const u64 *twp, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
+void build_twc_table(const u64 *nat_pairs, u32 logN, u32 s0, std::vector<u64> &out);
+u32 ntt_fast_s0(u32 logN);  // log2 slices per limb the fast kernel would use, or ~0u if it does not apply
+bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
                      u32 mod_count, bool inverse, u32 num_cus, hipStream_t st);
 void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, hipStream_t st);
 

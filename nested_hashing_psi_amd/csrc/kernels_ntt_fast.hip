@@ -19,6 +19,8 @@
 //
 // The ALU, not HBM, bounds this kernel: a 60-bit Shoup butterfly is ~10 v_mad_u64_u32 plus ~10 32-bit
 // adds/selects, 7 butterflies per 16 bytes moved (DESIGN.md "NTT roofline").
+#include <vector>
+
 #include "kernels.hpp"
 
 namespace piehip {
@@ -26,6 +28,7 @@ namespace piehip {
 struct NttFastArgs {
     u64 *data;
     const u64 *twp;  // interleaved {w, w_shoup} pairs: per modulus 2 tables (fwd, inv) of N pairs
+    const u64 *twc;  // the same pairs in pass-C kernel order (see build_twc_table)
     const DevConsts *dc;
     u32 N, logN;
     u32 s0;       // log2 slices per limb (stages below 2^s0 groups were done in global memory)
@@ -43,28 +46,31 @@ __device__ __forceinline__ u32 phi(u32 e) { return e + 2 * (e >> 5); }
 // the whole butterfly on the mad.  9 mads per modular multiplication:
 //   quotient estimate  qe = floor(b ws / 2^64) - {0,1,2}   from 3 partial products (b_lo ws_lo dropped)
 //   remainder          b w + qe (2^64 - q)  mod 2^64       as two accumulation chains (low word, cross terms)
-// The result lies in [0, 4q); with q < 2^60 the butterflies keep residues in [0, 8q) (forward) or
-// [0, 4q) (inverse) and normalise once at the end of the transform.
+// ws here is the 63-bit constant floor(w 2^63 / q) (= the usual Shoup constant >> 1) so that the sum of the
+// two cross products cannot overflow 64 bits for b < 2^63; qe = 2 bh sh + (bh sl + bl sh) >> 31 under-
+// estimates floor(b w / q) by at most 3.  The result lies in [0, 4q); with q < 2^60 the butterflies keep
+// residues in [0, 8q) (forward) or [0, 4q) (inverse) and normalise once at the end of the transform.
 __device__ __forceinline__ u64 mad_u(u32 a, u32 b, u64 c)
 {
     u64 d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
     return d;
 }
 __device__ __forceinline__ u64 mul_u(u32 a, u32 b)
 {
     u64 d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=&v"(d), "=s"(carry) : "v"(a), "v"(b));
     return d;
 }
-// b < 2^64, w < q, ws = floor(w 2^64 / q), nq = 2^64 - q: returns b w mod q + {0,1,2,3} q
+// b < 2^63, w < q, ws = floor(w 2^63 / q), nq = 2^64 - q: returns b w mod q + {0,1,2,3} q
 __device__ __forceinline__ u64 shoup4(u64 b, u64 w, u64 ws, u64 nq)
 {
     const u32 bl = (u32)b, bh = (u32)(b >> 32), wl = (u32)w, wh = (u32)(w >> 32);
     const u32 sl = (u32)ws, sh = (u32)(ws >> 32), nql = (u32)nq, nqh = (u32)(nq >> 32);
-    const u64 m1 = mul_u(bl, sh);
-    const u64 m2 = mad_u(bh, sl, m1 >> 32);
-    const u64 qe = mad_u(bh, sh, m2 >> 32);
+    const u64 m1 = mul_u(bl, sh);          // < 2^63  (sh < 2^31: ws is the 63-bit Shoup constant)
+    const u64 cr = mad_u(bh, sl, m1);      // both cross terms, < 2^64 for b < 2^63
+    const u64 top = mul_u(bh, sh);
+    const u64 qe = (top << 1) + (cr >> 31);
     u64 acc = mul_u((u32)qe, nql);
     acc = mad_u(bl, wl, acc);
     u64 c = mul_u((u32)qe, nqh);
@@ -92,9 +98,36 @@ __device__ __forceinline__ void gs_bfly(u64 &a, u64 &b, u64 w, u64 ws, u64 nq, u
     b = shoup4(d, w, ws, nq);
 }
 
+// LDS hand-off inside one wave: DS operations of a wave execute in issue order, so only the compiler has to
+// be kept from moving the reads above the writes
+#ifdef NTT_DBG_FULLSYNC
+#define WAVE_LOCAL_SYNC() __syncthreads()
+#else
+#define WAVE_LOCAL_SYNC()                                   \
+    do {                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+        __builtin_amdgcn_wave_barrier();                    \
+    } while (0)
+#endif
+
 // keeps hipcc from interleaving more than a few butterflies (each carries ~12 VGPRs of temporaries)
 #ifndef FENCE_EVERY
 #define FENCE_EVERY 16
+#endif
+#ifdef NTT_STAMPS
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (blockIdx.x == 0 && iter == 1) {                                                        \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            if (threadIdx.x == 0) gdata[(size_t)a.nitems * n + (i)] = t_;                          \
+            if (threadIdx.x == 448) gdata[(size_t)a.nitems * n + 32 + (i)] = t_;                    \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#else
+#define STAMP(i)
 #endif
 #define BFLY_FENCE(cnt, every)                                         \
     do {                                                               \
@@ -103,14 +136,22 @@ __device__ __forceinline__ void gs_bfly(u64 &a, u64 &b, u64 w, u64 ws, u64 nq, u
 
 template <int LOGN, bool INV>
 __global__ void __launch_bounds__((1 << LOGN) / 32)
-ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const DevConsts *__restrict__ gdc, NttFastArgs a)
+ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u64x2 *__restrict__ gtwc,
+                const DevConsts *__restrict__ gdc, NttFastArgs a)
 {
     constexpr u32 n = 1u << LOGN;   // coefficients in this slice
     constexpr u32 T = n / 32;       // threads
     constexpr u32 NB = n / 16;      // pass-B block size = pass-A row stride
     constexpr u32 SB = NB / 32;     // pass-B stride
     constexpr int C = LOGN - 9;     // pass-C stages
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    extern __shared__ __attribute__((aligned(16))) u64 lds_real[];
+#ifdef NTT_EXP_NOLDS
+    u64 *lds = lds_real + (threadIdx.x == 4096 ? 1 : 0);  // defeat alias analysis cheaply
+#define LDS_ON (threadIdx.x == 4097)
+#else
+    u64 *lds = lds_real;
+#define LDS_ON true
+#endif
 
     const u32 tau = threadIdx.x;
     const u32 beta = tau / SB, rho = tau % SB;
@@ -128,25 +169,14 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const De
             y[2 * k + 1] = v.y;
         }
     }
-    for (; item < a.nitems; item += gridDim.x) {
+    int iter = 0;
+    for (; item < a.nitems; item += gridDim.x, iter++) {
+        STAMP(0);
 #pragma unroll
         for (int k = 0; k < 32; k++) x[k] = y[k];
         const u32 next = item + gridDim.x;
         // forward: the next slice's loads fly during the whole transform (pass A has scalar twiddles, so
         // the 64 extra VGPRs fit); inverse: they are issued before pass A' instead (see below)
-#ifdef NTT_EXP_NOLOAD
-        if (!INV && next < a.nitems && tau == 1000) {
-#else
-        if (!INV && next < a.nitems) {
-#endif
-            const u64 *gn = gdata + (size_t)next * n;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const u64x2 v = *reinterpret_cast<const u64x2 *>(gn + 2 * tau + NB * k);
-                y[2 * k] = v.x;
-                y[2 * k + 1] = v.y;
-            }
-        }
         const u32 limb = item >> a.s0, blk = item & ((1u << a.s0) - 1);
         const u32 mod = a.mod_base + limb % a.mod_count;
         const Mod m = gdc->mod[mod];
@@ -154,8 +184,25 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const De
         // twiddle pairs of this modulus and direction; global group index of local group i at a stage
         // with ml local groups: (ml << s0) + blk * ml + i
         const u64x2 *__restrict__ tw = gtw + ((size_t)mod * 2 + (INV ? 1 : 0)) * a.N;
+        // pass-C twiddles in kernel order [blk][stage][j][tau]: lane-consecutive 16-byte loads (the natural
+        // order would touch 64 cache lines per wave instruction in the last stage)
+        constexpr u32 JT = 32 - (32 >> C);  // twiddles per thread over the C stages
+        const u64x2 *__restrict__ twc = gtwc + (((size_t)mod * 2 + (INV ? 1 : 0)) * (1u << a.s0) + blk) * (T * JT) + tau;
+#ifdef NTT_EXP_NOTW
+        const u64x2 wconst = tw[1];
+#define TWL(idx) wconst
+#define TWC(sc, j) wconst
+#else
+#define TWL(idx) tw[idx]
+#ifdef NTT_DBG_NATTW
+#define TWC(sc, j) tw[((512u << (sc)) << a.s0) + blk * (512u << (sc)) + (tau << (5 - C + (sc))) + (j)]
+#else
+#define TWC(sc, j) twc[T * ((32u >> C) * ((1u << (sc)) - 1) + (j))]
+#endif
+#endif
         u64 *g = gdata + (size_t)item * n;
 
+        STAMP(1);
         if (!INV) {
             // ---- pass A: stages with 1, 2, 4, 8 local groups; rows k, k + d ------------------------
 #pragma unroll
@@ -165,11 +212,13 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const De
                 for (int k = 0; k < 16; k++) {
                     if (k & d) continue;
                     const u32 ml = 1u << s, i = (u32)k >> (4 - s);
-                    const u64x2 w = tw[(ml << a.s0) + blk * ml + i];  // uniform: scalar load
+                    const u64x2 w = TWL((ml << a.s0) + blk * ml + i);  // uniform: scalar load
 #pragma unroll
                     for (int j = 0; j < 2; j++) ct_bfly(x[2 * k + j], x[2 * (k + d) + j], w.x, w.y, nq, q4);
                 }
             }
+            STAMP(2);
+            __syncthreads();  // every wave has finished the previous slice's copy-out reads
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 u64x2 v;
@@ -177,10 +226,13 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const De
                 v.y = x[2 * k + 1];
                 *reinterpret_cast<u64x2 *>(&lds[phi(2 * tau + NB * k)]) = v;
             }
+            STAMP(3);
             __syncthreads();
+            STAMP(4);
             // ---- pass B: 16 << sb local groups; columns rho + SB k of block beta ---------------------
 #pragma unroll
             for (int k = 0; k < 32; k++) x[k] = lds[phi(NB * beta + rho + SB * k)];
+            STAMP(5);
 #pragma unroll
             for (int sb = 0; sb < 5; sb++) {
                 const int d = 16 >> sb;
@@ -188,13 +240,16 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const De
                 for (int k = 0; k < 32; k++) {
                     if (k & d) continue;
                     const u32 ml = 16u << sb, i = (beta << sb) + ((u32)k >> (5 - sb));
-                    const u64x2 w = tw[(ml << a.s0) + blk * ml + i];
+                    const u64x2 w = TWL((ml << a.s0) + blk * ml + i);
                     ct_bfly(x[k], x[k + d], w.x, w.y, nq, q4);
                 }
             }
+            STAMP(6);
 #pragma unroll
             for (int k = 0; k < 32; k++) lds[phi(NB * beta + rho + SB * k)] = x[k];
-            __syncthreads();
+            STAMP(7);
+            WAVE_LOCAL_SYNC();  // a wave's pass-B blocks are exactly its pass-C rows (2048 contiguous elements)
+            STAMP(8);
             // ---- pass C: 512 << sc local groups; 32 contiguous coefficients ---------------------------
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -202,17 +257,33 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const De
                 x[2 * k] = v.x;
                 x[2 * k + 1] = v.y;
             }
+            STAMP(9);
+            // prefetch the next slice now: it lands during pass C, ahead of this slice's copy-out stores in the
+            // (in-order) vector-memory queue, and those stores then drain under the next slice's pass A
+#ifdef NTT_EXP_NOLOAD
+            if (next < a.nitems && tau == 1000) {
+#else
+            if (next < a.nitems) {
+#endif
+                const u64 *gn = gdata + (size_t)next * n;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const u64x2 v = *reinterpret_cast<const u64x2 *>(gn + 2 * tau + NB * k);
+                    y[2 * k] = v.x;
+                    y[2 * k + 1] = v.y;
+                }
+            }
 #pragma unroll
             for (int sc = 0; sc < C; sc++) {
                 const int d = 1 << (C - 1 - sc);
 #pragma unroll
                 for (int k = 0; k < 32; k++) {
                     if (k & d) continue;
-                    const u32 ml = 512u << sc, i = (tau << (5 - C + sc)) + ((u32)k >> (C - sc));
-                    const u64x2 w = tw[(ml << a.s0) + blk * ml + i];
+                    const u64x2 w = TWC(sc, (u32)k >> (C - sc));
                     ct_bfly(x[k], x[k + d], w.x, w.y, nq, q4);
                 }
             }
+            STAMP(10);
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 u64x2 v;
@@ -225,7 +296,9 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const De
                 v.y = r1 >= q ? r1 - q : r1;
                 *reinterpret_cast<u64x2 *>(&lds[phi(32 * tau + 2 * k)]) = v;
             }
+            STAMP(11);
             __syncthreads();
+            STAMP(12);
             // ---- coalesced copy-out -------------------------------------------------------------------
 #ifndef NTT_EXP_NOSTORE
 #pragma unroll
@@ -234,7 +307,8 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const De
 #else
             if (tau == 1000) g[0] = lds[phi(tau)];
 #endif
-            __syncthreads();
+            STAMP(13);
+            STAMP(14);
         } else {
             // ---- copy-in through LDS to reach the 32-contiguous layout ------------------------------------
 #pragma unroll
@@ -258,8 +332,7 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const De
 #pragma unroll
                 for (int k = 0; k < 32; k++) {
                     if (k & d) continue;
-                    const u32 ml = 512u << sc, i = (tau << (5 - C + sc)) + ((u32)k >> (C - sc));
-                    const u64x2 w = tw[(ml << a.s0) + blk * ml + i];
+                    const u64x2 w = TWC(sc, (u32)k >> (C - sc));
                     gs_bfly(x[k], x[k + d], w.x, w.y, nq, q4);
                     BFLY_FENCE(k, FENCE_EVERY);
                 }
@@ -271,7 +344,7 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const De
                 v.y = x[2 * k + 1];
                 *reinterpret_cast<u64x2 *>(&lds[phi(32 * tau + 2 * k)]) = v;
             }
-            __syncthreads();
+            WAVE_LOCAL_SYNC();
             // ---- pass B' -----------------------------------------------------------------------------------------
 #pragma unroll
             for (int k = 0; k < 32; k++) x[k] = lds[phi(NB * beta + rho + SB * k)];
@@ -282,7 +355,7 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const De
                 for (int k = 0; k < 32; k++) {
                     if (k & d) continue;
                     const u32 ml = 16u << sb, i = (beta << sb) + ((u32)k >> (5 - sb));
-                    const u64x2 w = tw[(ml << a.s0) + blk * ml + i];
+                    const u64x2 w = TWL((ml << a.s0) + blk * ml + i);
                     gs_bfly(x[k], x[k + d], w.x, w.y, nq, q4);
                     BFLY_FENCE(k, FENCE_EVERY);
                 }
@@ -314,7 +387,7 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const De
                 for (int k = 0; k < 16; k++) {
                     if (k & d) continue;
                     const u32 ml = 1u << s, i = (u32)k >> (4 - s);
-                    const u64x2 w = tw[(ml << a.s0) + blk * ml + i];
+                    const u64x2 w = TWL((ml << a.s0) + blk * ml + i);
 #pragma unroll
                     for (int j = 0; j < 2; j++) gs_bfly(x[2 * k + j], x[2 * (k + d) + j], w.x, w.y, nq, q4);
                     BFLY_FENCE(k, FENCE_EVERY / 2);
@@ -350,11 +423,33 @@ static void launch_one(const NttFastArgs &a, u32 max_groups, hipStream_t st)
         attr = true;
     }
     u32 grid = a.nitems < max_groups ? a.nitems : max_groups;
-    hipLaunchKernelGGL((ntt_fast_kernel<LOGN, INV>), dim3(grid), dim3(n / 32), lds, st, a.data, reinterpret_cast<const u64x2 *>(a.twp), a.dc, a);
+    hipLaunchKernelGGL((ntt_fast_kernel<LOGN, INV>), dim3(grid), dim3(n / 32), lds, st, a.data, reinterpret_cast<const u64x2 *>(a.twp), reinterpret_cast<const u64x2 *>(a.twc), a.dc, a);
 }
 
 // returns false if this slice size has no register-blocked kernel
-bool launch_ntt_fast(const u64 *twp, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
+// Host side: pass-C twiddles of one (modulus, direction) in kernel order [blk][stage][j][tau].
+// nat[k] = {w, w_shoup} pairs in natural (bit-reversed exponent) order, N pairs.
+void build_twc_table(const u64 *nat, u32 logN, u32 s0, std::vector<u64> &out)
+{
+    const u32 logn = logN - s0, n = 1u << logn, T = n / 32;
+    const int C = (int)logn - 9;
+    const u32 JT = 32 - (32 >> C);
+    out.assign((size_t)(1u << s0) * T * JT * 2, 0);
+    for (u32 blk = 0; blk < (1u << s0); blk++)
+        for (int sc = 0; sc < C; sc++) {
+            const u32 ml = 512u << sc, J = 1u << (5 - C + sc);
+            for (u32 j = 0; j < J; j++)
+                for (u32 tau = 0; tau < T; tau++) {
+                    const u32 i = (tau << (5 - C + sc)) + j;
+                    const size_t src = (size_t)((ml << s0) + blk * ml + i) * 2;
+                    const size_t dst = (((size_t)blk * T * JT) + (size_t)T * ((32u >> C) * ((1u << sc) - 1) + j) + tau) * 2;
+                    out[dst] = nat[src];
+                    out[dst + 1] = nat[src + 1];
+                }
+        }
+}
+
+bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
                      u32 mod_count, bool inverse, u32 num_cus, hipStream_t st)
 {
     const u32 logn = logN - s0;
@@ -362,6 +457,7 @@ bool launch_ntt_fast(const u64 *twp, const DevConsts *dc, u32 N, u32 logN, u32 s
     NttFastArgs a;
     a.data = data;
     a.twp = twp;
+    a.twc = twc;
     a.dc = dc;
     a.N = N;
     a.logN = logN;

@@ -60,6 +60,7 @@ struct piehip_ctx {
     DevConsts *d_dc = nullptr;
     u64 *d_tables = nullptr;  // [(M+1)][4][N]
     u64 *d_twp = nullptr;     // [(M+1)][2][N][2] interleaved {w, w_shoup}
+    u64 *d_twc = nullptr;     // pass-C kernel-order copy of the same pairs
     u32 *d_inv_pos = nullptr; // EVALUATION position -> slot
     NttPlan plan;
     // keys / database / inputs
@@ -286,13 +287,27 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
             for (u32 k = 0; k < N; k++) {
                 u64 *f = &pairs[((size_t)a * 2 + 0) * 2 * N + 2 * (size_t)k];
                 u64 *i = &pairs[((size_t)a * 2 + 1) * 2 * N + 2 * (size_t)k];
+                // the register-blocked kernel uses 63-bit Shoup constants floor(w 2^63 / q) (kernels_ntt_fast.hip)
                 f[0] = h->hp.tw[a][k];
-                f[1] = h->hp.tw_sh[a][k];
+                f[1] = h->hp.tw_sh[a][k] >> 1;
                 i[0] = h->hp.itw[a][k];
-                i[1] = h->hp.itw_sh[a][k];
+                i[1] = h->hp.itw_sh[a][k] >> 1;
             }
         CHK_(hipMalloc((void **)&h->d_twp, pairs.size() * sizeof(u64)));
         CHK_(hipMemcpy(h->d_twp, pairs.data(), pairs.size() * sizeof(u64), hipMemcpyHostToDevice));
+        u32 s0 = ntt_fast_s0(h->hp.logN);
+        for (u32 a = 0; a <= M; a++)
+            if (h->hp.moduli[a] >> 60) s0 = ~0u;  // lazy residues need 8q < 2^63
+        if (s0 != ~0u) {
+            std::vector<u64> all, one;
+            for (u32 a = 0; a <= M; a++)
+                for (u32 dir = 0; dir < 2; dir++) {
+                    build_twc_table(&pairs[((size_t)a * 2 + dir) * 2 * N], h->hp.logN, s0, one);
+                    all.insert(all.end(), one.begin(), one.end());
+                }
+            CHK_(hipMalloc((void **)&h->d_twc, all.size() * sizeof(u64)));
+            CHK_(hipMemcpy(h->d_twc, all.data(), all.size() * sizeof(u64), hipMemcpyHostToDevice));
+        }
     }
     {
         std::vector<u32> inv(N, 0xFFFFFFFFu);
@@ -303,6 +318,7 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
 #undef CHK_
     h->plan.tables = h->d_tables;
     h->plan.twp = h->d_twp;
+    h->plan.twc = h->d_twc;
     h->plan.force_generic = false;
     {
         hipDeviceProp_t prop;
@@ -334,6 +350,7 @@ int piehip_destroy(piehip_handle h)
     if (h->d_dc) (void)hipFree(h->d_dc);
     if (h->d_tables) (void)hipFree(h->d_tables);
     if (h->d_twp) (void)hipFree(h->d_twp);
+    if (h->d_twc) (void)hipFree(h->d_twc);
     if (h->d_inv_pos) (void)hipFree(h->d_inv_pos);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -777,7 +794,11 @@ int piehip_bench_ntt(piehip_handle h, uint32_t nlimbs, uint32_t mod_count, int i
     Tmp tmp;
     const u32 N = h->hp.N;
     const size_t words = (size_t)nlimbs * N;
+#ifdef NTT_STAMPS
+    TMPGET(d, words + 64);
+#else
     TMPGET(d, words);
+#endif
     {   // residues below the smallest modulus are valid for every limb
         std::vector<u64> host(words);
         u64 lo = h->hp.moduli[0];
@@ -802,6 +823,17 @@ int piehip_bench_ntt(piehip_handle h, uint32_t nlimbs, uint32_t mod_count, int i
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *ms_per_launch = (double)ms / iters;
+#ifdef NTT_STAMPS
+    {
+        u64 st[64];
+        HIPCHK(hipMemcpy(st, d + words, sizeof(st), hipMemcpyDeviceToHost));
+        for (int w = 0; w < 2; w++) {
+            fprintf(stderr, "stamps wave%d (cycles since iteration start):", w * 7);
+            for (int i = 1; i < 15; i++) fprintf(stderr, " [%d]%lld", i, (long long)(st[32 * w + i] - st[32 * w]));
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     return PIEHIP_OK;
 }
 

@@ -25,9 +25,10 @@ __device__ __forceinline__ u64 shoup4(u64 b, u64 w, u64 ws, u64 nq)
 {
     const u32 bl = (u32)b, bh = (u32)(b >> 32), wl = (u32)w, wh = (u32)(w >> 32), sl = (u32)ws, sh = (u32)(ws >> 32);
     const u32 nql = (u32)nq, nqh = (u32)(nq >> 32);
-    const u64 m1 = mul_u(bl, sh);
-    const u64 m2 = mad_u(bh, sl, m1 >> 32);
-    const u64 qe = mad_u(bh, sh, m2 >> 32);
+    const u64 m1 = mul_u(bl, sh);          // < 2^63  (sh < 2^31: ws is the 63-bit Shoup constant)
+    const u64 cr = mad_u(bh, sl, m1);      // both cross terms, < 2^64 for b < 2^63
+    const u64 top = mul_u(bh, sh);
+    const u64 qe = (top << 1) + (cr >> 31);
     u64 acc = mul_u((u32)qe, nql);
     acc = mad_u(bl, wl, acc);
     u64 c = mul_u((u32)qe, nqh);
@@ -68,13 +69,13 @@ __global__ void __launch_bounds__(256) probe(u64 *out, u64 seed, u64 q, u64 w, u
                     x[c] = u - t + 2 * q;
                 }
             } else if (OP == 12) {  // asm Shoup [0,4q)
-                x[c] = shoup4(x[c], w, wsh, 0 - q);
+                x[c] = shoup4(x[c] >> 1, w, wsh >> 1, 0 - q);
             } else if (OP == 13) {  // asm butterfly, [0,8q) invariant
                 if (c & 1) {
                     u64 u = x[c - 1], v = x[c];
                     const u64 q4 = 4 * q;
                     u = u >= q4 ? u - q4 : u;
-                    u64 t = shoup4(v, w, wsh, 0 - q);
+                    u64 t = shoup4(v >> 1, w, wsh >> 1, 0 - q);
                     x[c - 1] = u + t;
                     x[c] = u - t + q4;
                 }
@@ -84,7 +85,7 @@ __global__ void __launch_bounds__(256) probe(u64 *out, u64 seed, u64 q, u64 w, u
                     const u64 q4 = 4 * q;
                     const u64 tt = u - q4;
                     u = (long long)tt < 0 ? u : tt;
-                    u64 t = shoup4(v, w, wsh, 0 - q);
+                    u64 t = shoup4(v >> 1, w, wsh >> 1, 0 - q);
                     x[c - 1] = u + t;
                     x[c] = u - t + q4;
                 }
