@@ -25,8 +25,12 @@ struct NttPlan {
 void build_twc_table(const u64 *nat_pairs, u32 logN, u32 s0, std::vector<u64> &out);
 u32 ntt_fast_s0(u32 logN);  // log2 slices per limb the fast kernel would use, or ~0u if it does not apply
 bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
-                     u32 mod_count, bool inverse, u32 num_cus, hipStream_t st);
-void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, hipStream_t st);
+                     u32 mod_count, bool inverse, bool sigma, u32 num_cus, hipStream_t st);
+void ntt_sigma_inverse_map(u32 logN, std::vector<u32> &map);
+// sigma: keep the EVALUATION side in the register-blocked kernel's lane order (internal arrays only; ignored,
+// i.e. standard order, when that kernel does not apply -- ntt_sigma_inverse_map is then the identity)
+void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, hipStream_t st,
+                bool sigma = false);
 
 // Stage A: acc[b][K][2][L][N] = sum_j idx[h][j] (.) db[h][beta][j] + minus    (BatchedFHEHIPPIE.cpp:101-116)
 void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
@@ -47,8 +51,9 @@ void launch_scale_round(const DevConsts *dc, u32 N, u32 L, const u64 *d, u32 nb,
 // BV digits: d2c at d2 + bin*stride2 ([L][N], COEFFICIENT) -> dig[nb][L(i)][L(j)][N] (centred lift of residue i into q_j)
 void launch_digits(const DevConsts *dc, u32 N, u32 L, const u64 *d2, size_t stride2, u32 nb, u64 *dig, hipStream_t st);
 // out[bin][c][j] = (d01[bin][c][j] + sum_i dig[bin][i][j] (.) key[i][c][j]) (.) mask[bin][j]   (mask may be null)
+// out_map (may be null): coefficient n of the result is written to position out_map[n] (lane order -> standard)
 void launch_relin_mac(const DevConsts *dc, u32 N, u32 L, const u64 *d01, size_t stride01, const u64 *dig, const u64 *key,
-                      const u64 *mask, u64 *out, u32 nb, hipStream_t st);
+                      const u64 *mask, u64 *out, u32 nb, hipStream_t st, const u32 *out_map = nullptr);
 // element-wise helpers on nct ciphertexts [nct][2][L][N]
 void launch_ct_add(const DevConsts *dc, u32 N, u32 L, const u64 *x, const u64 *y, u64 *out, u32 nct, hipStream_t st);
 void launch_ct_mul_plain(const DevConsts *dc, u32 N, u32 L, const u64 *x, const u64 *pt, size_t pt_stride, u64 *out,

@@ -140,7 +140,7 @@ u32 ntt_fast_s0(u32 logN)
     return (logN - s0 >= 12 && logN - s0 <= 14) ? s0 : ~0u;
 }
 
-void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, hipStream_t st)
+void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, hipStream_t st, bool sigma)
 {
     if (!nlimbs) return;
     NttArgs a;
@@ -172,10 +172,10 @@ void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_
     if (!inverse) {
         for (u32 ms = 1; ms < (1u << a.s0); ms <<= 1)
             hipLaunchKernelGGL(ntt_global_stage<false>, ggrid, dim3(256), 0, st, a, ms, 0u);
-        if (!(fast_ok && launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, a.s0, data, nlimbs, mod_base, mod_count, false, pl.num_cus, st)))
+        if (!(fast_ok && launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, a.s0, data, nlimbs, mod_base, mod_count, false, sigma, pl.num_cus, st)))
             hipLaunchKernelGGL(ntt_lds_generic<false>, dim3(nlimbs << a.s0), dim3(threads), lds, st, a);
     } else {
-        if (!(fast_ok && launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, a.s0, data, nlimbs, mod_base, mod_count, true, pl.num_cus, st)))
+        if (!(fast_ok && launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, a.s0, data, nlimbs, mod_base, mod_count, true, sigma, pl.num_cus, st)))
             hipLaunchKernelGGL(ntt_lds_generic<true>, dim3(nlimbs << a.s0), dim3(threads), lds, st, a);
         for (u32 ms = (1u << a.s0) >> 1; ms >= 1; ms >>= 1)
             hipLaunchKernelGGL(ntt_global_stage<true>, ggrid, dim3(256), 0, st, a, ms, ms == 1 ? 1u : 0u);

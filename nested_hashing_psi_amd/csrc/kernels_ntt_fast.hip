@@ -17,6 +17,13 @@
 // pass-C rows (ds_read_b128, lane stride 272 B), the stride-n/512 pass-B columns and the pair-wise
 // pass-A rows are all bank-conflict-free or at worst 2-way.
 //
+// Lane order ("sigma" layout).  The evaluation side of a transform ends (forward) or starts (inverse) with
+// 32 contiguous coefficients per thread, which is uncoalesced in memory; the standard order therefore costs
+// one more LDS transpose and barrier.  For arrays that never leave the library (the QP operands and the
+// tensor result between the forward and inverse transforms, the key-switch digits) the kernel can instead
+// store pair k of thread tau at 2 (k T + tau): coalesced, no transpose.  Point-wise kernels do not care
+// about the order; key and mask get a sigma-ordered copy at load time (ntt_sigma_inverse_map).
+//
 // The ALU, not HBM, bounds this kernel: a 60-bit Shoup butterfly is ~10 v_mad_u64_u32 plus ~10 32-bit
 // adds/selects, 7 butterflies per 16 bytes moved (DESIGN.md "NTT roofline").
 #include <vector>
@@ -33,6 +40,7 @@ struct NttFastArgs {
     u32 N, logN;
     u32 s0;       // log2 slices per limb (stages below 2^s0 groups were done in global memory)
     u32 nitems;   // limbs << s0
+    u32 sigma;    // EVALUATION side stored in lane order (see below) instead of standard bit-reversed order
     u32 mod_base, mod_count;
 };
 
@@ -80,7 +88,38 @@ __device__ __forceinline__ u64 shoup4(u64 b, u64 w, u64 ws, u64 nq)
     return acc + ((u64)(u32)c << 32);
 }
 
-// Harvey butterflies on lazy residues ---------------------------------------------------------------
+// two independent products with the dependent mad chains interleaved statement by statement: hipcc keeps
+// source order for the asm statements, and back-to-back dependent v_mad_u64_u32 leave the multiplier idle
+__device__ __forceinline__ void shoup4x2(u64 b0, u64 w0, u64 s0, u64 b1, u64 w1, u64 s1, u64 nq, u64 &r0, u64 &r1)
+{
+    const u32 b0l = (u32)b0, b0h = (u32)(b0 >> 32), w0l = (u32)w0, w0h = (u32)(w0 >> 32), s0l = (u32)s0, s0h = (u32)(s0 >> 32);
+    const u32 b1l = (u32)b1, b1h = (u32)(b1 >> 32), w1l = (u32)w1, w1h = (u32)(w1 >> 32), s1l = (u32)s1, s1h = (u32)(s1 >> 32);
+    const u32 nql = (u32)nq, nqh = (u32)(nq >> 32);
+    const u64 m0 = mul_u(b0l, s0h);
+    const u64 m1 = mul_u(b1l, s1h);
+    const u64 t0 = mul_u(b0h, s0h);
+    const u64 t1 = mul_u(b1h, s1h);
+    const u64 c0 = mad_u(b0h, s0l, m0);
+    const u64 c1 = mad_u(b1h, s1l, m1);
+    const u64 q0 = (t0 << 1) + (c0 >> 31);
+    const u64 q1 = (t1 << 1) + (c1 >> 31);
+    u64 a0 = mul_u((u32)q0, nql);
+    u64 a1 = mul_u((u32)q1, nql);
+    u64 x0 = mul_u((u32)q0, nqh);
+    u64 x1 = mul_u((u32)q1, nqh);
+    a0 = mad_u(b0l, w0l, a0);
+    a1 = mad_u(b1l, w1l, a1);
+    x0 = mad_u((u32)(q0 >> 32), nql, x0);
+    x1 = mad_u((u32)(q1 >> 32), nql, x1);
+    x0 = mad_u(b0l, w0h, x0);
+    x1 = mad_u(b1l, w1h, x1);
+    x0 = mad_u(b0h, w0l, x0);
+    x1 = mad_u(b1h, w1l, x1);
+    r0 = a0 + ((u64)(u32)x0 << 32);
+    r1 = a1 + ((u64)(u32)x1 << 32);
+}
+
+// Harvey butterflies on lazy residues ------------------------------------------------------------------------
 // forward: inputs in [0, 8q), outputs in [0, 8q)
 __device__ __forceinline__ void ct_bfly(u64 &a, u64 &b, u64 w, u64 ws, u64 nq, u64 q4)
 {
@@ -97,6 +136,31 @@ __device__ __forceinline__ void gs_bfly(u64 &a, u64 &b, u64 w, u64 ws, u64 nq, u
     a = s >= q4 ? s - q4 : s;
     b = shoup4(d, w, ws, nq);
 }
+// (two-at-a-time variants: measured no faster forward and spill in the 2^14 inverse; kept for experiments)
+// forward: inputs in [0, 8q), outputs in [0, 8q)
+__device__ __forceinline__ void ct_bfly2(u64 &a0, u64 &b0, u64 &a1, u64 &b1, u64x2 w0, u64x2 w1, u64 nq, u64 q4)
+{
+    u64 v0, v1;
+    shoup4x2(b0, w0.x, w0.y, b1, w1.x, w1.y, nq, v0, v1);
+    const u64 u0 = a0 >= q4 ? a0 - q4 : a0;
+    const u64 u1 = a1 >= q4 ? a1 - q4 : a1;
+    a0 = u0 + v0;
+    a1 = u1 + v1;
+    b0 = u0 - v0 + q4;
+    b1 = u1 - v1 + q4;
+}
+// inverse: inputs in [0, 4q), outputs in [0, 4q)
+__device__ __forceinline__ void gs_bfly2(u64 &a0, u64 &b0, u64 &a1, u64 &b1, u64x2 w0, u64x2 w1, u64 nq, u64 q4)
+{
+    const u64 s0 = a0 + b0, s1 = a1 + b1;
+    const u64 d0 = a0 - b0 + q4, d1 = a1 - b1 + q4;
+    a0 = s0 >= q4 ? s0 - q4 : s0;
+    a1 = s1 >= q4 ? s1 - q4 : s1;
+    shoup4x2(d0, w0.x, w0.y, d1, w1.x, w1.y, nq, b0, b1);
+}
+
+// m-th index in [0,32) whose bit `d` (a power of two) is clear
+__device__ __forceinline__ constexpr int bfly_lo(int m, int d) { return ((m & ~(d - 1)) << 1) | (m & (d - 1)); }
 
 // LDS hand-off inside one wave: DS operations of a wave execute in issue order, so only the compiler has to
 // be kept from moving the reads above the writes
@@ -134,7 +198,7 @@ __device__ __forceinline__ void gs_bfly(u64 &a, u64 &b, u64 w, u64 ws, u64 nq, u
         if (((cnt) % (every)) == (every) - 1) __builtin_amdgcn_sched_barrier(0); \
     } while (0)
 
-template <int LOGN, bool INV>
+template <int LOGN, bool INV, bool SIGMA>
 __global__ void __launch_bounds__((1 << LOGN) / 32)
 ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u64x2 *__restrict__ gtwc,
                 const DevConsts *__restrict__ gdc, NttFastArgs a)
@@ -162,9 +226,10 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
     // prefetch the first slice (A-layout addresses are also the coalesced copy-in/out order)
     {
         const u64 *g = gdata + (size_t)item * n;
+        const u32 st = (INV && SIGMA) ? 2 * T : NB;  // sigma order: pair k of thread tau at 2 (k T + tau)
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const u64x2 v = *reinterpret_cast<const u64x2 *>(g + 2 * tau + NB * k);
+            const u64x2 v = *reinterpret_cast<const u64x2 *>(g + 2 * tau + st * k);
             y[2 * k] = v.x;
             y[2 * k + 1] = v.y;
         }
@@ -216,6 +281,27 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
 #pragma unroll
                     for (int j = 0; j < 2; j++) ct_bfly(x[2 * k + j], x[2 * (k + d) + j], w.x, w.y, nq, q4);
                 }
+                if (s == 0) {
+                    // Prefetch the next slice here: the previous slice's stores have had one stage to drain (the
+                    // vector-memory queue is in order, loads issued right behind 128 KiB of stores stall at issue),
+                    // pass A needs no vector loads (scalar twiddles), and the data is home before pass B's twiddle
+                    // loads queue up behind it.
+                    __builtin_amdgcn_sched_barrier(0);
+#ifdef NTT_EXP_NOLOAD
+                    if (next < a.nitems && tau == 1000) {
+#else
+                    if (next < a.nitems) {
+#endif
+                        const u64 *gn = gdata + (size_t)next * n;
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const u64x2 v = *reinterpret_cast<const u64x2 *>(gn + 2 * tau + NB * k);
+                            y[2 * k] = v.x;
+                            y[2 * k + 1] = v.y;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             STAMP(2);
             __syncthreads();  // every wave has finished the previous slice's copy-out reads
@@ -237,10 +323,10 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
             for (int sb = 0; sb < 5; sb++) {
                 const int d = 16 >> sb;
 #pragma unroll
-                for (int k = 0; k < 32; k++) {
-                    if (k & d) continue;
-                    const u32 ml = 16u << sb, i = (beta << sb) + ((u32)k >> (5 - sb));
-                    const u64x2 w = TWL((ml << a.s0) + blk * ml + i);
+                for (int mm = 0; mm < 16; mm++) {
+                    const int k = bfly_lo(mm, d);
+                    const u32 ml = 16u << sb;
+                    const u64x2 w = TWL((ml << a.s0) + blk * ml + (beta << sb) + ((u32)k >> (5 - sb)));
                     ct_bfly(x[k], x[k + d], w.x, w.y, nq, q4);
                 }
             }
@@ -258,32 +344,32 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
                 x[2 * k + 1] = v.y;
             }
             STAMP(9);
-            // prefetch the next slice now: it lands during pass C, ahead of this slice's copy-out stores in the
-            // (in-order) vector-memory queue, and those stores then drain under the next slice's pass A
-#ifdef NTT_EXP_NOLOAD
-            if (next < a.nitems && tau == 1000) {
-#else
-            if (next < a.nitems) {
-#endif
-                const u64 *gn = gdata + (size_t)next * n;
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const u64x2 v = *reinterpret_cast<const u64x2 *>(gn + 2 * tau + NB * k);
-                    y[2 * k] = v.x;
-                    y[2 * k + 1] = v.y;
-                }
-            }
 #pragma unroll
             for (int sc = 0; sc < C; sc++) {
                 const int d = 1 << (C - 1 - sc);
 #pragma unroll
-                for (int k = 0; k < 32; k++) {
-                    if (k & d) continue;
+                for (int mm = 0; mm < 16; mm++) {
+                    const int k = bfly_lo(mm, d);
                     const u64x2 w = TWC(sc, (u32)k >> (C - sc));
                     ct_bfly(x[k], x[k + d], w.x, w.y, nq, q4);
                 }
             }
             STAMP(10);
+            if (SIGMA) {  // lane order: straight from registers, coalesced
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    u64x2 v;
+                    u64 r0 = x[2 * k], r1 = x[2 * k + 1];
+                    r0 = r0 >= q4 ? r0 - q4 : r0;
+                    r1 = r1 >= q4 ? r1 - q4 : r1;
+                    r0 = r0 >= q2 ? r0 - q2 : r0;
+                    r1 = r1 >= q2 ? r1 - q2 : r1;
+                    v.x = r0 >= q ? r0 - q : r0;
+                    v.y = r1 >= q ? r1 - q : r1;
+                    *reinterpret_cast<u64x2 *>(g + 2 * (k * T + tau)) = v;
+                }
+                continue;
+            }
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 u64x2 v;
@@ -310,31 +396,33 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
             STAMP(13);
             STAMP(14);
         } else {
-            // ---- copy-in through LDS to reach the 32-contiguous layout ------------------------------------
+            // ---- standard order: copy-in through LDS to reach the 32-contiguous layout (lane order has it) -
+            if (!SIGMA) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                u64x2 v;
-                v.x = x[2 * k];
-                v.y = x[2 * k + 1];
-                *reinterpret_cast<u64x2 *>(&lds[phi(2 * tau + NB * k)]) = v;
-            }
-            __syncthreads();
+                for (int k = 0; k < 16; k++) {
+                    u64x2 v;
+                    v.x = x[2 * k];
+                    v.y = x[2 * k + 1];
+                    *reinterpret_cast<u64x2 *>(&lds[phi(2 * tau + NB * k)]) = v;
+                }
+                __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const u64x2 v = *reinterpret_cast<const u64x2 *>(&lds[phi(32 * tau + 2 * k)]);
-                x[2 * k] = v.x;
-                x[2 * k + 1] = v.y;
+                for (int k = 0; k < 16; k++) {
+                    const u64x2 v = *reinterpret_cast<const u64x2 *>(&lds[phi(32 * tau + 2 * k)]);
+                    x[2 * k] = v.x;
+                    x[2 * k + 1] = v.y;
+                }
             }
             // ---- pass C': distances 1, 2, .. 2^(C-1) -----------------------------------------------------------
 #pragma unroll
             for (int sc = C - 1; sc >= 0; sc--) {
                 const int d = 1 << (C - 1 - sc);
 #pragma unroll
-                for (int k = 0; k < 32; k++) {
-                    if (k & d) continue;
+                for (int mm = 0; mm < 16; mm++) {
+                    const int k = bfly_lo(mm, d);
                     const u64x2 w = TWC(sc, (u32)k >> (C - sc));
                     gs_bfly(x[k], x[k + d], w.x, w.y, nq, q4);
-                    BFLY_FENCE(k, FENCE_EVERY);
+                    BFLY_FENCE(mm, FENCE_EVERY);
                 }
             }
 #pragma unroll
@@ -352,12 +440,12 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
             for (int sb = 4; sb >= 0; sb--) {
                 const int d = 16 >> sb;
 #pragma unroll
-                for (int k = 0; k < 32; k++) {
-                    if (k & d) continue;
-                    const u32 ml = 16u << sb, i = (beta << sb) + ((u32)k >> (5 - sb));
-                    const u64x2 w = TWL((ml << a.s0) + blk * ml + i);
+                for (int mm = 0; mm < 16; mm++) {
+                    const int k = bfly_lo(mm, d);
+                    const u32 ml = 16u << sb;
+                    const u64x2 w = TWL((ml << a.s0) + blk * ml + (beta << sb) + ((u32)k >> (5 - sb)));
                     gs_bfly(x[k], x[k + d], w.x, w.y, nq, q4);
-                    BFLY_FENCE(k, FENCE_EVERY);
+                    BFLY_FENCE(mm, FENCE_EVERY);
                 }
             }
 #pragma unroll
@@ -373,9 +461,10 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
             __syncthreads();  // the next slice's copy-in overwrites the image
             if (next < a.nitems) {  // prefetch: latency hides behind pass A' (scalar twiddles, low pressure)
                 const u64 *gn = gdata + (size_t)next * n;
+                const u32 st = SIGMA ? 2 * T : NB;
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    const u64x2 v = *reinterpret_cast<const u64x2 *>(gn + 2 * tau + NB * k);
+                    const u64x2 v = *reinterpret_cast<const u64x2 *>(gn + 2 * tau + st * k);
                     y[2 * k] = v.x;
                     y[2 * k + 1] = v.y;
                 }
@@ -412,18 +501,18 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
     }
 }
 
-template <int LOGN, bool INV>
+template <int LOGN, bool INV, bool SIGMA>
 static void launch_one(const NttFastArgs &a, u32 max_groups, hipStream_t st)
 {
     constexpr u32 n = 1u << LOGN;
     constexpr size_t lds = (size_t)(n + n / 16) * sizeof(u64);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void *)ntt_fast_kernel<LOGN, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)ntt_fast_kernel<LOGN, INV, SIGMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     u32 grid = a.nitems < max_groups ? a.nitems : max_groups;
-    hipLaunchKernelGGL((ntt_fast_kernel<LOGN, INV>), dim3(grid), dim3(n / 32), lds, st, a.data, reinterpret_cast<const u64x2 *>(a.twp), reinterpret_cast<const u64x2 *>(a.twc), a.dc, a);
+    hipLaunchKernelGGL((ntt_fast_kernel<LOGN, INV, SIGMA>), dim3(grid), dim3(n / 32), lds, st, a.data, reinterpret_cast<const u64x2 *>(a.twp), reinterpret_cast<const u64x2 *>(a.twc), a.dc, a);
 }
 
 // returns false if this slice size has no register-blocked kernel
@@ -449,8 +538,27 @@ void build_twc_table(const u64 *nat, u32 logN, u32 s0, std::vector<u64> &out)
         }
 }
 
+// lane-order position p (within the limb) -> standard position; identity when the register-blocked kernel
+// does not apply to this ring dimension
+void ntt_sigma_inverse_map(u32 logN, std::vector<u32> &map)
+{
+    const u32 N = 1u << logN;
+    map.resize(N);
+    const u32 s0 = ntt_fast_s0(logN);
+    if (s0 == ~0u) {
+        for (u32 p = 0; p < N; p++) map[p] = p;
+        return;
+    }
+    const u32 n = N >> s0, T = n / 32;
+    for (u32 p = 0; p < N; p++) {
+        const u32 blk = p / n, pl = p % n;
+        const u32 tau = (pl >> 1) % T, k = (pl >> 1) / T;
+        map[p] = blk * n + 32 * tau + 2 * k + (pl & 1);
+    }
+}
+
 bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
-                     u32 mod_count, bool inverse, u32 num_cus, hipStream_t st)
+                     u32 mod_count, bool inverse, bool sigma, u32 num_cus, hipStream_t st)
 {
     const u32 logn = logN - s0;
     if (logn < 12 || logn > 14) return false;
@@ -463,18 +571,26 @@ bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N,
     a.logN = logN;
     a.s0 = s0;
     a.nitems = nlimbs << s0;
+    a.sigma = sigma ? 1u : 0u;
     a.mod_base = mod_base;
     a.mod_count = mod_count;
     // resident workgroups per CU by LDS: 136 KiB -> 1, 68 KiB -> 2, 34 KiB -> 4
     const u32 per_cu = logn == 14 ? 1 : (logn == 13 ? 2 : 4);
     const u32 maxg = num_cus * per_cu;
-    if (logn == 14) {
-        if (inverse) launch_one<14, true>(a, maxg, st); else launch_one<14, false>(a, maxg, st);
-    } else if (logn == 13) {
-        if (inverse) launch_one<13, true>(a, maxg, st); else launch_one<13, false>(a, maxg, st);
-    } else {
-        if (inverse) launch_one<12, true>(a, maxg, st); else launch_one<12, false>(a, maxg, st);
-    }
+#define NTT_DISPATCH(LG)                                                          \
+    do {                                                                          \
+        if (inverse) {                                                            \
+            if (sigma) launch_one<LG, true, true>(a, maxg, st);                   \
+            else launch_one<LG, true, false>(a, maxg, st);                        \
+        } else {                                                                  \
+            if (sigma) launch_one<LG, false, true>(a, maxg, st);                  \
+            else launch_one<LG, false, false>(a, maxg, st);                       \
+        }                                                                         \
+    } while (0)
+    if (logn == 14) NTT_DISPATCH(14);
+    else if (logn == 13) NTT_DISPATCH(13);
+    else NTT_DISPATCH(12);
+#undef NTT_DISPATCH
     return true;
 }
 

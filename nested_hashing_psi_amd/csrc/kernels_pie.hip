@@ -241,7 +241,7 @@ void launch_digits(const DevConsts *dc, u32 N, u32 L, const u64 *d2, size_t stri
 __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *dc, u32 N, u32 L, const u64 *__restrict__ d01,
                                                         size_t stride01, const u64 *__restrict__ dig,
                                                         const u64 *__restrict__ key, const u64 *__restrict__ mask,
-                                                        u64 *__restrict__ out)
+                                                        u64 *__restrict__ out, const u32 *__restrict__ out_map)
 {
     const u32 n = blockIdx.x * TPB + threadIdx.x;
     if (n >= N) return;
@@ -253,13 +253,13 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *dc, u32
         mac128(acc, dig[(((size_t)bin * L + i) * L + j) * N + n], key[(((size_t)i * 2 + c) * L + j) * N + n]);
     u64 r = addmod(reduce128(acc, m), d01[(size_t)bin * stride01 + (size_t)c * LN + (size_t)j * N + n], m.q);
     if (mask) r = mulmod(r, mask[(size_t)bin * LN + (size_t)j * N + n], m);
-    out[((size_t)bin * 2 + c) * LN + (size_t)j * N + n] = r;
+    out[((size_t)bin * 2 + c) * LN + (size_t)j * N + (out_map ? out_map[n] : n)] = r;
 }
 void launch_relin_mac(const DevConsts *dc, u32 N, u32 L, const u64 *d01, size_t stride01, const u64 *dig, const u64 *key,
-                      const u64 *mask, u64 *out, u32 nb, hipStream_t st)
+                      const u64 *mask, u64 *out, u32 nb, hipStream_t st, const u32 *out_map)
 {
     dim3 grid((N + TPB - 1) / TPB, 2 * L, nb);
-    hipLaunchKernelGGL(relin_mac_kernel, grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out);
+    hipLaunchKernelGGL(relin_mac_kernel, grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map);
 }
 
 // ---------------------------------------------------------------------------------------------

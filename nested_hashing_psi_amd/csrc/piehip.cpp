@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -62,6 +63,9 @@ struct piehip_ctx {
     u64 *d_twp = nullptr;     // [(M+1)][2][N][2] interleaved {w, w_shoup}
     u64 *d_twc = nullptr;     // pass-C kernel-order copy of the same pairs
     u32 *d_inv_pos = nullptr; // EVALUATION position -> slot
+    u32 *d_sigma_inv = nullptr;  // lane-order position -> standard position (identity for small rings)
+    bool sigma_on = false;       // the register-blocked NTT (and hence the lane order) applies to this context
+    u64 *d_evk_sigma = nullptr, *d_masks_sigma = nullptr;  // lane-ordered copies of key and masks
     NttPlan plan;
     // keys / database / inputs
     u64 *d_evk = nullptr;
@@ -158,15 +162,16 @@ static void ws_free(MulWs &w)
 }
 
 // ---- schedule pieces ----------------------------------------------------------------------------
-static void ntt(piehip_ctx *h, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inv)
+static void ntt(piehip_ctx *h, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inv, bool sigma = false)
 {
     ProfScope ps(h, inv ? PIEHIP_K_NTT_INV : PIEHIP_K_NTT_FWD, 16.0 * h->hp.N * nlimbs);
-    launch_ntt(h->plan, data, nlimbs, mod_base, mod_count, inv, h->stream);
+    launch_ntt(h->plan, data, nlimbs, mod_base, mod_count, inv, h->stream, sigma && h->sigma_on);
 }
 
 // BV key switch of the COEFFICIENT-format polynomials at w.d2c with `key`, added to the EVALUATION
 // ciphertexts at w.d01, optionally multiplied by mask plaintexts: out[nb][2][L][N]
-static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, const u64 *mask, u64 *out)
+// sigma: w.d01 and the digits are in lane order, key/mask are lane-ordered copies, out is written in standard order
+static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, const u64 *mask, u64 *out, bool sigma = false)
 {
     const u32 N = h->hp.N, L = h->hp.L;
     const size_t LN = h->LN();
@@ -175,10 +180,11 @@ static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, c
         ProfScope ps(h, PIEHIP_K_DIGITS, W * nb * (L + (double)L * L));
         launch_digits(h->d_dc, N, L, w.d2c, LN, nb, w.dig, h->stream);
     }
-    ntt(h, w.dig, nb * L * L, 0, L, false);
+    ntt(h, w.dig, nb * L * L, 0, L, false, sigma);
     {
         ProfScope ps(h, PIEHIP_K_RELIN, W * (nb * ((double)L * L + 2 * L + 2 * L + (mask ? L : 0)) + 2.0 * L * L));
-        launch_relin_mac(h->d_dc, N, L, w.d01, 2 * LN, w.dig, key, mask, out, nb, h->stream);
+        launch_relin_mac(h->d_dc, N, L, w.d01, 2 * LN, w.dig, key, mask, out, nb, h->stream,
+                         (sigma && h->sigma_on) ? h->d_sigma_inv : nullptr);
     }
 }
 
@@ -196,19 +202,20 @@ static void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const 
         launch_expand_q_to_qp(h->d_dc, N, L, x, sx, LN, nb, w.eqp, 4, 0, h->stream);
         launch_scale_pq_expand(h->d_dc, N, L, y, sy, LN, nb, w.eqp, 4, 2, h->stream);
     }
-    ntt(h, w.eqp, nb * 4 * M, 0, M, false);
+    // the QP operands and the tensor result never leave the library: lane order, no LDS transposes
+    ntt(h, w.eqp, nb * 4 * M, 0, M, false, true);
     {
         ProfScope ps(h, PIEHIP_K_TENSOR, W * nb * 7.0 * M);
         launch_tensor(h->d_dc, N, M, w.eqp, w.dqp, nb, h->stream);
     }
-    ntt(h, w.dqp, nb * 3 * M, 0, M, true);
+    ntt(h, w.dqp, nb * 3 * M, 0, M, true, true);
     if (relin) {
         {
             ProfScope ps(h, PIEHIP_K_SCALE, W * nb * (3.0 * M + 3.0 * L));
             launch_scale_round(h->d_dc, N, L, w.dqp, nb, w.d01, 2 * LN, w.d2c, LN, h->stream);
         }
-        ntt(h, w.d01, nb * 2 * L, 0, L, false);
-        enqueue_keyswitch(h, w, nb, h->d_evk, mask, out);
+        ntt(h, w.d01, nb * 2 * L, 0, L, false, true);
+        enqueue_keyswitch(h, w, nb, h->sigma_on ? h->d_evk_sigma : h->d_evk, mask, out, true);
     } else {
         {
             ProfScope ps(h, PIEHIP_K_SCALE, W * nb * (3.0 * M + 3.0 * L));
@@ -317,6 +324,16 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
     }
 #undef CHK_
     h->plan.tables = h->d_tables;
+    {
+        std::vector<u32> smap;
+        ntt_sigma_inverse_map(h->hp.logN, smap);
+        if (hipMalloc((void **)&h->d_sigma_inv, sizeof(u32) * N) != hipSuccess ||
+            hipMemcpy(h->d_sigma_inv, smap.data(), sizeof(u32) * N, hipMemcpyHostToDevice) != hipSuccess) {
+            piehip_destroy(h);
+            return fail(PIEHIP_EHIP, "sigma map upload failed");
+        }
+        h->sigma_on = h->d_twc != nullptr;
+    }
     h->plan.twp = h->d_twp;
     h->plan.twc = h->d_twc;
     h->plan.force_generic = false;
@@ -352,6 +369,9 @@ int piehip_destroy(piehip_handle h)
     if (h->d_twp) (void)hipFree(h->d_twp);
     if (h->d_twc) (void)hipFree(h->d_twc);
     if (h->d_inv_pos) (void)hipFree(h->d_inv_pos);
+    if (h->d_sigma_inv) (void)hipFree(h->d_sigma_inv);
+    dev_free(&h->d_evk_sigma);
+    dev_free(&h->d_masks_sigma);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PIEHIP_OK;
@@ -396,6 +416,27 @@ int piehip_load_relin_key(piehip_handle h, const uint64_t *evk)
         if (rc) return rc;
     }
     HIPCHK(hipMemcpy(h->d_evk, evk, words * sizeof(u64), hipMemcpyHostToDevice));
+    if (h->sigma_on) {  // lane-ordered copy for the key-switch MAC
+        if (!h->d_evk_sigma) {
+            int rc = dev_alloc(&h->d_evk_sigma, words);
+            if (rc) return rc;
+        }
+        launch_permute(h->hp.N, h->d_evk, h->d_sigma_inv, h->d_evk_sigma, h->hp.L * 2 * h->hp.L, h->stream);
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return PIEHIP_OK;
+}
+
+// lane-ordered copy of the mask plaintexts for the fused mask multiply of the last key switch
+static int make_masks_sigma(piehip_ctx *h)
+{
+    if (!h->sigma_on) return PIEHIP_OK;
+    dev_free(&h->d_masks_sigma);
+    int rc = dev_alloc(&h->d_masks_sigma, (size_t)h->b * h->LN());
+    if (rc) return rc;
+    launch_permute(h->hp.N, h->d_masks, h->d_sigma_inv, h->d_masks_sigma, h->b * h->hp.L, h->stream);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail(PIEHIP_EHIP, std::string("mask permutation: ") + hipGetErrorString(e));
     return PIEHIP_OK;
 }
 
@@ -406,6 +447,7 @@ static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E)
     const size_t LN = h->LN();
     dev_free(&h->d_db);
     dev_free(&h->d_masks);
+    dev_free(&h->d_masks_sigma);
     dev_free(&h->d_acc);
     dev_free(&h->d_prod);
     dev_free(&h->d_out);
@@ -437,7 +479,7 @@ int piehip_load_db(piehip_handle h, uint32_t K, uint32_t b, uint32_t E, const ui
     const size_t LN = h->LN();
     HIPCHK(hipMemcpy(h->d_db, pts, sizeof(u64) * (size_t)K * b * E * LN, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_masks, masks, sizeof(u64) * (size_t)b * LN, hipMemcpyHostToDevice));
-    return PIEHIP_OK;
+    return make_masks_sigma(h);
 }
 
 // device-side MakePackedPlaintext of npt slot vectors (already on the device) into out[npt][L][N]
@@ -481,7 +523,8 @@ int piehip_load_db_slots(piehip_handle h, uint32_t K, uint32_t b, uint32_t E, ui
     if (e == hipSuccess && rc == PIEHIP_OK) rc = encode_on_device(h, d_s, b, B, h->d_masks);
     (void)hipFree(d_s);
     if (e != hipSuccess) return fail(PIEHIP_EHIP, std::string("load_db_slots: ") + hipGetErrorString(e));
-    return rc;
+    if (rc) return rc;
+    return make_masks_sigma(h);
 }
 
 int piehip_set_index(piehip_handle h, const uint64_t *idx)
@@ -555,7 +598,7 @@ int piehip_run(piehip_handle h)
     for (u32 hf = 1; hf < K; hf++) {
         const bool last = hf + 1 == K;
         u64 *dst = last ? h->d_out : h->d_prod;
-        enqueue_mul(h, h->ws, x, sx, h->d_acc + (size_t)hf * 2 * LN, (size_t)K * 2 * LN, b, true, last ? h->d_masks : nullptr, dst);
+        enqueue_mul(h, h->ws, x, sx, h->d_acc + (size_t)hf * 2 * LN, (size_t)K * 2 * LN, b, true, last ? (h->sigma_on ? h->d_masks_sigma : h->d_masks) : nullptr, dst);
         if (!last) {
             ntt(h, h->d_prod, b * 2 * L, 0, L, true);
             x = h->d_prod;
@@ -813,9 +856,10 @@ int piehip_bench_ntt(piehip_handle h, uint32_t nlimbs, uint32_t mod_count, int i
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    launch_ntt(h->plan, d, nlimbs, 0, mod_count, inverse != 0, h->stream);  // warm-up
+    const bool sigma = getenv("PIEHIP_BENCH_SIGMA") != nullptr && h->sigma_on;  // tooling switch: lane-order side
+    launch_ntt(h->plan, d, nlimbs, 0, mod_count, inverse != 0, h->stream, sigma);  // warm-up
     HIPCHK(hipEventRecord(e0, h->stream));
-    for (u32 i = 0; i < iters; i++) launch_ntt(h->plan, d, nlimbs, 0, mod_count, inverse != 0, h->stream);
+    for (u32 i = 0; i < iters; i++) launch_ntt(h->plan, d, nlimbs, 0, mod_count, inverse != 0, h->stream, sigma);
     HIPCHK(hipEventRecord(e1, h->stream));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0;

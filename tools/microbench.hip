@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef uint64_t u64;
 typedef uint32_t u32;
 #define ITER 4096
@@ -39,7 +40,7 @@ __device__ __forceinline__ u64 shoup4(u64 b, u64 w, u64 ws, u64 nq)
 }
 
 template <int OP>
-__global__ void __launch_bounds__(256) probe(u64 *out, u64 seed, u64 q, u64 w, u64 wsh)
+__global__ void __launch_bounds__(512) probe(u64 *out, u64 seed, u64 q, u64 w, u64 wsh)
 {
     u64 x[CH];
     for (int c = 0; c < CH; c++) x[c] = seed * (threadIdx.x + 1 + c * 977) + blockIdx.x;
@@ -114,26 +115,27 @@ __global__ void __launch_bounds__(256) probe(u64 *out, u64 seed, u64 q, u64 w, u
     }
     u64 r = 0;
     for (int c = 0; c < CH; c++) r ^= x[c];
-    out[blockIdx.x * 256 + threadIdx.x] = r;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+static int g_blocks_per_cu = 8, g_threads = 256;
 template <int OP>
 static void run(const char *name, double ops_per_iter_chain, u64 *d)
 {
-    const int blocks = 256 * 8;
+    const int blocks = 256 * g_blocks_per_cu;
     u64 q = (1ULL << 60) - 33 * 32768 + 1, w = 0x0123456789abcdefULL % q, wsh = (u64)(((unsigned __int128)w << 64) / q);
     hipEvent_t a, b;
     hipEventCreate(&a);
     hipEventCreate(&b);
-    hipLaunchKernelGGL(probe<OP>, dim3(blocks), dim3(256), 0, 0, d, 0x9E3779B97F4A7C15ULL, q, w, wsh);
+    hipLaunchKernelGGL(probe<OP>, dim3(blocks), dim3(g_threads), 0, 0, d, 0x9E3779B97F4A7C15ULL, q, w, wsh);
     hipDeviceSynchronize();
     hipEventRecord(a, 0);
-    for (int r = 0; r < 5; r++) hipLaunchKernelGGL(probe<OP>, dim3(blocks), dim3(256), 0, 0, d, 0x9E3779B97F4A7C15ULL + r, q, w, wsh);
+    for (int r = 0; r < 5; r++) hipLaunchKernelGGL(probe<OP>, dim3(blocks), dim3(g_threads), 0, 0, d, 0x9E3779B97F4A7C15ULL + r, q, w, wsh);
     hipEventRecord(b, 0);
     hipEventSynchronize(b);
     float ms;
     hipEventElapsedTime(&ms, a, b);
-    double total = 5.0 * blocks * 256 * (double)ITER * CH * ops_per_iter_chain;
+    double total = 5.0 * blocks * g_threads * (double)ITER * CH * ops_per_iter_chain;
     double gops = total / (ms * 1e-3) / 1e9;
     // lanes per clock per CU at 2.4 GHz (256 CUs)
     double per_cu_clk = gops * 1e9 / 256 / 2.4e9;
@@ -141,10 +143,12 @@ static void run(const char *name, double ops_per_iter_chain, u64 *d)
            per_cu_clk, 64.0 * 4 / per_cu_clk);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 2) { g_blocks_per_cu = atoi(argv[1]); g_threads = atoi(argv[2]); }
+    printf("blocks/CU %d threads %d -> %d waves/SIMD\n", g_blocks_per_cu, g_threads, g_blocks_per_cu * g_threads / 256);
     u64 *d;
-    hipMalloc((void **)&d, 256 * 8 * 256 * 8);
+    hipMalloc((void **)&d, 256 * 8 * 512 * 8);
     run<0>("mad_u64_u32", 1, d);
     run<1>("mul_lo_u32", 1, d);
     run<2>("mul_hi_u32", 1, d);
