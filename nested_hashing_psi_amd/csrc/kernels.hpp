@@ -33,8 +33,9 @@ void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_
                 bool sigma = false);
 
 // Stage A: acc[b][K][2][L][N] = sum_j idx[h][j] (.) db[h][beta][j] + minus    (BatchedFHEHIPPIE.cpp:101-116)
+// small_moduli: every RNS modulus is < 2^60 (enables the v_mad_u64_u32 column-accumulator kernel)
 void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
-                    const u64 *db, u64 *acc, hipStream_t st);
+                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli);
 
 // Base conversions, COEFFICIENT format.  Polynomial (o, c), o < n_outer, c < 2,
 // is read at in + o*in_stride_outer + c*in_stride_inner ([L][N] limbs) and written to

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "madasm.h"
 
 namespace piehip {
 
@@ -58,18 +59,6 @@ __device__ __forceinline__ u32 phi(u32 e) { return e + 2 * (e >> 5); }
 // two cross products cannot overflow 64 bits for b < 2^63; qe = 2 bh sh + (bh sl + bl sh) >> 31 under-
 // estimates floor(b w / q) by at most 3.  The result lies in [0, 4q); with q < 2^60 the butterflies keep
 // residues in [0, 8q) (forward) or [0, 4q) (inverse) and normalise once at the end of the transform.
-__device__ __forceinline__ u64 mad_u(u32 a, u32 b, u64 c)
-{
-    u64 d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ u64 mul_u(u32 a, u32 b)
-{
-    u64 d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=&v"(d), "=s"(carry) : "v"(a), "v"(b));
-    return d;
-}
 // b < 2^63, w < q, ws = floor(w 2^63 / q), nq = 2^64 - q: returns b w mod q + {0,1,2,3} q
 __device__ __forceinline__ u64 shoup4(u64 b, u64 w, u64 ws, u64 nq)
 {

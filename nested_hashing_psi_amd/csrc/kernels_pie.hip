@@ -5,6 +5,7 @@
 // lanes on consecutive coefficients (coalesced 8-byte or 16-byte lanes), constants scalar-loaded
 // from one DevConsts block.  Reference call sites: BatchedFHEHIPPIE.cpp:101-127.
 #include "kernels.hpp"
+#include "madasm.h"
 
 namespace piehip {
 
@@ -12,44 +13,184 @@ static const u32 TPB = 256;
 
 // ---------------------------------------------------------------------------------------------
 // Stage A (rows A3+A4): acc[beta][h][c][l][n] = sum_j idx[h][j][c][l][n] * db[h][beta][j][l][n] + minus[c][l][n]
-// 128-bit lazy accumulation, one Barrett reduction per 32 terms.
+//
+// HBM-bound: every database plaintext limb is read exactly once per run() (b K E L W bytes, 196 MiB at C3).
+// A thread owns two adjacent coefficients (16-byte lanes) of one (h, limb) and BPT bin layers: the two index
+// ciphertext components are loaded once per j and reused for all BPT layers, so index traffic is
+// (b / BPT) K E 2L W instead of b K E 2L W; the BPT database loads per j are independent streams in flight.
+// 128-bit lazy accumulation (products < 2^120, E < 128 terms), one Barrett reduction at the end.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E,
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+template <int BPT>
+__global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
                                                       const u64 *__restrict__ idx, const u64 *__restrict__ minus,
                                                       const u64 *__restrict__ db, u64 *__restrict__ acc)
 {
-    const u32 n = blockIdx.x * TPB + threadIdx.x;
+    const u32 n = 2 * (blockIdx.x * TPB + threadIdx.x);
     const u32 l = blockIdx.y;
-    const u32 beta = blockIdx.z / K, h = blockIdx.z % K;
+    const u32 groups = b / BPT;
+    const u32 h = blockIdx.z / groups, beta0 = (blockIdx.z % groups) * BPT;
     if (n >= N) return;
     const Mod m = dc->mod[l];
     const size_t LN = (size_t)L * N;
     const u64 *pi = idx + ((size_t)h * E) * 2 * LN + (size_t)l * N + n;
-    const u64 *pd = db + (((size_t)h * b + beta) * E) * LN + (size_t)l * N + n;
-    U128 a0 = {0, 0}, a1 = {0, 0};
+    const u64 *pd = db + (((size_t)h * b + beta0) * E) * LN + (size_t)l * N + n;
+    const size_t bin_stride = (size_t)E * LN;
+    U128 a[BPT][2][2];
+#pragma unroll
+    for (int t = 0; t < BPT; t++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) a[t][c][0] = a[t][c][1] = U128{0, 0};
     for (u32 j = 0; j < E; j++) {
-        const u64 d = pd[(size_t)j * LN];
-        const u64 i0 = pi[(size_t)j * 2 * LN];
-        const u64 i1 = pi[(size_t)j * 2 * LN + LN];
-        mac128(a0, i0, d);
-        mac128(a1, i1, d);
-        if ((j & 31) == 31) {
-            a0.lo = reduce128(a0, m);
-            a0.hi = 0;
-            a1.lo = reduce128(a1, m);
-            a1.hi = 0;
+        const u64x2 i0 = *reinterpret_cast<const u64x2 *>(pi + (size_t)j * 2 * LN);
+        const u64x2 i1 = *reinterpret_cast<const u64x2 *>(pi + (size_t)j * 2 * LN + LN);
+        u64x2 d[BPT];
+#pragma unroll
+        for (int t = 0; t < BPT; t++) d[t] = *reinterpret_cast<const u64x2 *>(pd + (size_t)t * bin_stride + (size_t)j * LN);
+#pragma unroll
+        for (int t = 0; t < BPT; t++) {
+            mac128(a[t][0][0], i0.x, d[t].x);
+            mac128(a[t][0][1], i0.y, d[t].y);
+            mac128(a[t][1][0], i1.x, d[t].x);
+            mac128(a[t][1][1], i1.y, d[t].y);
+        }
+        if ((j & 127) == 127) {
+#pragma unroll
+            for (int t = 0; t < BPT; t++)
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int e = 0; e < 2; e++) a[t][c][e] = U128{reduce128(a[t][c][e], m), 0};
         }
     }
-    u64 *po = acc + (((size_t)beta * K + h) * 2) * LN + (size_t)l * N + n;
-    po[0] = addmod(reduce128(a0, m), minus[(size_t)l * N + n], m.q);
-    po[LN] = addmod(reduce128(a1, m), minus[LN + (size_t)l * N + n], m.q);
+    const u64x2 m0 = *reinterpret_cast<const u64x2 *>(minus + (size_t)l * N + n);
+    const u64x2 m1 = *reinterpret_cast<const u64x2 *>(minus + LN + (size_t)l * N + n);
+#pragma unroll
+    for (int t = 0; t < BPT; t++) {
+        u64 *po = acc + (((size_t)(beta0 + t) * K + h) * 2) * LN + (size_t)l * N + n;
+        u64x2 r0, r1;
+        r0.x = addmod(reduce128(a[t][0][0], m), m0.x, m.q);
+        r0.y = addmod(reduce128(a[t][0][1], m), m0.y, m.q);
+        r1.x = addmod(reduce128(a[t][1][0], m), m1.x, m.q);
+        r1.y = addmod(reduce128(a[t][1][1], m), m1.y, m.q);
+        *reinterpret_cast<u64x2 *>(po) = r0;
+        *reinterpret_cast<u64x2 *>(po + LN) = r1;
+    }
+}
+
+// Same work with carry-free column accumulators on v_mad_u64_u32 (madasm.h): the 128-bit form above is bound by
+// its 64x64->128 multiplies (46 SIMD cycles each, 3.9 TB/s at C3), this one by HBM.  Needs every modulus
+// < 2^60 and E <= COLACC_MAX_TOTAL (one carry sweep after 8 terms keeps the columns from overflowing).
+template <int BPT, int CPT>
+__global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
+                                                          const u64 *__restrict__ idx, const u64 *__restrict__ minus,
+                                                          const u64 *__restrict__ db, u64 *__restrict__ acc)
+{
+    // CPT coefficients per thread: 2 -> 16-byte lanes; 1 -> 8-byte lanes, half the accumulator registers
+    const u32 n = CPT * (blockIdx.x * TPB + threadIdx.x);
+    const u32 l = blockIdx.y;
+    const u32 groups = b / BPT;
+    const u32 h = blockIdx.z / groups, beta0 = (blockIdx.z % groups) * BPT;
+    if (n >= N) return;
+    const Mod m = dc->mod[l];
+    const size_t LN = (size_t)L * N;
+    const u64 *pi = idx + ((size_t)h * E) * 2 * LN + (size_t)l * N + n;
+    const u64 *pd = db + (((size_t)h * b + beta0) * E) * LN + (size_t)l * N + n;
+    const size_t bin_stride = (size_t)E * LN;
+    ColAcc a[BPT][2][CPT];
+#pragma unroll
+    for (int t = 0; t < BPT; t++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int e = 0; e < CPT; e++) a[t][c][e] = ColAcc{0, 0, 0};
+    for (u32 j0 = 0; j0 < E; j0 += COLACC_MAX_TERMS) {
+        const u32 j1 = j0 + COLACC_MAX_TERMS < E ? j0 + COLACC_MAX_TERMS : E;
+        for (u32 j = j0; j < j1; j++) {
+            u64 iv[2][CPT], dv[BPT][CPT];
+            if (CPT == 2) {
+                const u64x2 i0 = *reinterpret_cast<const u64x2 *>(pi + (size_t)j * 2 * LN);
+                const u64x2 i1 = *reinterpret_cast<const u64x2 *>(pi + (size_t)j * 2 * LN + LN);
+                iv[0][0] = i0.x, iv[0][CPT - 1] = i0.y, iv[1][0] = i1.x, iv[1][CPT - 1] = i1.y;
+#pragma unroll
+                for (int t = 0; t < BPT; t++) {
+                    const u64x2 d = *reinterpret_cast<const u64x2 *>(pd + (size_t)t * bin_stride + (size_t)j * LN);
+                    dv[t][0] = d.x, dv[t][CPT - 1] = d.y;
+                }
+            } else {
+                iv[0][0] = pi[(size_t)j * 2 * LN];
+                iv[1][0] = pi[(size_t)j * 2 * LN + LN];
+#pragma unroll
+                for (int t = 0; t < BPT; t++) dv[t][0] = pd[(size_t)t * bin_stride + (size_t)j * LN];
+            }
+            Split30 is[2][CPT];
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int e = 0; e < CPT; e++) is[c][e] = split30(iv[c][e]);
+#pragma unroll
+            for (int t = 0; t < BPT; t++)
+#pragma unroll
+                for (int e = 0; e < CPT; e++) {
+                    const Split30 ds = split30(dv[t][e]);
+                    colacc_mac(a[t][0][e], is[0][e], ds);
+                    colacc_mac(a[t][1][e], is[1][e], ds);
+                }
+        }
+        if (j1 < E) {  // another chunk follows: make room in the low columns
+#pragma unroll
+            for (int t = 0; t < BPT; t++)
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int e = 0; e < CPT; e++) colacc_carry(a[t][c][e]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < BPT; t++) {
+        u64 *po = acc + (((size_t)(beta0 + t) * K + h) * 2) * LN + (size_t)l * N + n;
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int e = 0; e < CPT; e++)
+                po[(size_t)c * LN + e] = addmod(reduce128(colacc_value(a[t][c][e]), m), minus[(size_t)c * LN + (size_t)l * N + n + e], m.q);
+    }
 }
 
 void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
-                    const u64 *db, u64 *acc, hipStream_t st)
+                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli)
 {
-    dim3 grid((N + TPB - 1) / TPB, L, b * K);
-    hipLaunchKernelGGL(stage_a_kernel, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc);
+    // bin layers per thread: the largest divisor of b that keeps the accumulators in registers
+    const bool mad = small_moduli && E <= COLACC_MAX_TOTAL;
+    const int cap = mad ? 7 : 8;
+    int bpt = 1;
+    for (int c = cap; c >= 1; c--)
+        if (b % c == 0) {
+            bpt = c;
+            break;
+        }
+    // the mad kernel keeps 6 accumulator registers per (layer, component, coefficient): above 4 layers per
+    // thread it handles one coefficient per thread (8-byte lanes) to stay at >= 2 waves per SIMD
+    const int cpt = (mad && bpt > 4) ? 1 : 2;
+    dim3 grid((N / cpt + TPB - 1) / TPB, L, K * (b / bpt));
+#define SA(B_)                                                                                                       \
+    do {                                                                                                             \
+        if (mad && cpt == 1) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 1>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc); \
+        else if (mad) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 2>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc); \
+        else hipLaunchKernelGGL(stage_a_kernel<B_>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc);  \
+    } while (0)
+    switch (bpt) {
+        case 8: hipLaunchKernelGGL(stage_a_kernel<8>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc); break;
+        case 7: SA(7); break;
+        case 6: SA(6); break;
+        case 5: SA(5); break;
+        case 4: SA(4); break;
+        case 3: SA(3); break;
+        case 2: SA(2); break;
+        default: SA(1); break;
+    }
+#undef SA
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -65,8 +206,8 @@ __device__ __forceinline__ u64 crt_out(const u64 *y, u32 ns, const u64 *hat, u32
 {
     U128 acc = {0, 0};
     for (u32 i = 0; i < ns; i++) mac128(acc, y[i], hat[(size_t)i * hat_stride]);
-    const u64 s = reduce128(acc, tm);
-    return submod(s, mulmod(v, prodmod, tm), tm.q);
+    mac128(acc, v, tm.q - prodmod);  // - v * prodmod (mod tm); v <= ns: one Barrett reduction for the whole sum
+    return reduce128(acc, tm);
 }
 
 __global__ void __launch_bounds__(TPB) expand_q_to_qp_kernel(const DevConsts *dc, u32 N, u32 L, const u64 *__restrict__ in,
@@ -121,7 +262,8 @@ __global__ void __launch_bounds__(TPB) scale_pq_expand_kernel(const DevConsts *d
         const Mod &pj = dc->mod[L + j];
         U128 acc = {0, 0};
         for (u32 i = 0; i < L; i++) mac128(acc, y[i], dc->PI_modp[i][j]);
-        const u64 r = addmod(reduce128(acc, pj), reduce128(itot, pj), pj.q);
+        add128(acc, itot);
+        const u64 r = reduce128(acc, pj);
         pout[(size_t)(L + j) * N] = r;
         yp[j] = mul_shoup(r, dc->phat_inv[j], dc->phat_inv_sh[j], pj.q);
         fs2 += fixfrac(yp[j], pj);
@@ -206,7 +348,8 @@ __global__ void __launch_bounds__(TPB) scale_round_kernel(const DevConsts *dc, u
         const Mod &qk = dc->mod[k];
         U128 acc = mul128(pin[(size_t)k * N], dc->tPinv_modq[k]);
         for (u32 j = 0; j < Lp; j++) mac128(acc, yp[j], dc->tQF_modq[j][k]);
-        pout[(size_t)k * N] = addmod(reduce128(acc, qk), reduce128(itot, qk), qk.q);
+        add128(acc, itot);
+        pout[(size_t)k * N] = reduce128(acc, qk);
     }
 }
 void launch_scale_round(const DevConsts *dc, u32 N, u32 L, const u64 *d, u32 nb, u64 *out01, size_t stride01, u64 *out2,

@@ -1,0 +1,68 @@
+// madasm.h -- v_mad_u64_u32 based multiply-accumulate helpers (device only, gfx950).
+//
+// v_mad_u64_u32 (32x32+64 -> 64) issues at twice the rate of v_mul_lo_u32 / v_mul_hi_u32 on gfx950
+// (tools/microbench.hip: 5.1 vs 9 cycles per wave64 op per SIMD), and hipcc narrows every 64-bit product
+// whose high half is unused to v_mul_lo_u32; inline asm keeps the hot loops on the mad.
+#pragma once
+#include "modarith.h"
+
+namespace piehip {
+
+__device__ __forceinline__ u64 mad_u(u32 a, u32 b, u64 c)
+{
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ u64 mul_u(u32 a, u32 b)
+{
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=&v"(d), "=s"(carry) : "v"(a), "v"(b));
+    return d;
+}
+
+// Carry-free accumulation of products of residues < 2^60: operands are split into 30-bit halves and the
+// three product columns (2^0, 2^30, 2^60) are summed in separate 64-bit words.  Every partial product is
+// < 2^60, so up to 16 terms fit without overflow (column 1 takes two products per term: up to 8 terms
+// ... see COLACC_MAX_TERMS).  4 mads per term, no carries, no wait states.
+struct Split30 {
+    u32 lo, hi;
+};
+__device__ __forceinline__ Split30 split30(u64 x)
+{
+    Split30 s;
+    s.lo = (u32)x & 0x3FFFFFFFu;
+    s.hi = (u32)(x >> 30);
+    return s;
+}
+struct ColAcc {
+    u64 c0, c1, c2;
+};
+static const u32 COLACC_MAX_TERMS = 8;  // column 1 receives 2 products < 2^60 per term: 16 * 2^60 = 2^64
+__device__ __forceinline__ void colacc_mac(ColAcc &a, Split30 x, Split30 y)
+{
+    a.c0 = mad_u(x.lo, y.lo, a.c0);
+    a.c1 = mad_u(x.lo, y.hi, a.c1);
+    a.c1 = mad_u(x.hi, y.lo, a.c1);
+    a.c2 = mad_u(x.hi, y.hi, a.c2);
+}
+// push the overflow of the two low columns upwards (value unchanged): after it c0, c1 < 2^30, so another
+// COLACC_MAX_TERMS terms fit; the top column then holds up to 15 terms' worth before it overflows
+static const u32 COLACC_MAX_TOTAL = 15;
+__device__ __forceinline__ void colacc_carry(ColAcc &a)
+{
+    a.c1 += a.c0 >> 30;
+    a.c0 &= 0x3FFFFFFFull;
+    a.c2 += a.c1 >> 30;
+    a.c1 &= 0x3FFFFFFFull;
+}
+// c0 + c1 2^30 + c2 2^60 as a 128-bit integer
+__device__ __forceinline__ U128 colacc_value(const ColAcc &a)
+{
+    U128 r = {a.c0, 0};
+    add128(r, U128{a.c1 << 30, a.c1 >> 34});
+    add128(r, U128{a.c2 << 60, a.c2 >> 4});
+    return r;
+}
+
+}  // namespace piehip

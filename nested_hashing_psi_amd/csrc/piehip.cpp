@@ -64,6 +64,7 @@ struct piehip_ctx {
     u64 *d_twc = nullptr;     // pass-C kernel-order copy of the same pairs
     u32 *d_inv_pos = nullptr; // EVALUATION position -> slot
     u32 *d_sigma_inv = nullptr;  // lane-order position -> standard position (identity for small rings)
+    bool small_moduli = false;   // all Q and P moduli < 2^60
     bool sigma_on = false;       // the register-blocked NTT (and hence the lane order) applies to this context
     u64 *d_evk_sigma = nullptr, *d_masks_sigma = nullptr;  // lane-ordered copies of key and masks
     NttPlan plan;
@@ -333,6 +334,9 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
             return fail(PIEHIP_EHIP, "sigma map upload failed");
         }
         h->sigma_on = h->d_twc != nullptr;
+        h->small_moduli = true;
+        for (u32 a = 0; a < M; a++)
+            if (h->hp.moduli[a] >> 60) h->small_moduli = false;
     }
     h->plan.twp = h->d_twp;
     h->plan.twc = h->d_twc;
@@ -587,7 +591,7 @@ int piehip_run(piehip_handle h)
     h->pool_used = 0;
     {   // stage A: all inner products of all bin layers in one launch (BatchedFHEHIPPIE.cpp:101-116)
         ProfScope ps(h, PIEHIP_K_STAGE_A, W * ((double)b * K * E * L + (double)K * E * 2 * L + 2.0 * L + (double)b * K * 2 * L));
-        launch_stage_a(h->d_dc, N, L, K, b, E, h->d_idx, h->d_minus, h->d_db, h->d_acc, h->stream);
+        launch_stage_a(h->d_dc, N, L, K, b, E, h->d_idx, h->d_minus, h->d_db, h->d_acc, h->stream, h->small_moduli);
     }
     // every accumulator enters a ct x ct product exactly once: switch them all to COEFFICIENT format
     ntt(h, h->d_acc, b * K * 2 * L, 0, L, true);
