@@ -14,6 +14,7 @@ struct NttPlan {
     const u64 *tables;
     const u64 *twp;       // interleaved {w, w_shoup} pairs: per modulus [fwd N pairs][inv N pairs]
     const u64 *twc;       // pass-C twiddles in kernel order: per modulus [fwd][inv], see build_twc_table
+    const u64 *twc_fold;  // the same for the folded configuration (two half-size slices per limb), or null
     const DevConsts *dc;  // device pointer
     u32 N, logN;
     u32 num_cus;
@@ -26,31 +27,42 @@ void build_twc_table(const u64 *nat_pairs, u32 logN, u32 s0, std::vector<u64> &o
 u32 ntt_fast_s0(u32 logN);  // log2 slices per limb the fast kernel would use, or ~0u if it does not apply
 bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
                      u32 mod_count, bool inverse, bool sigma, u32 num_cus, hipStream_t st);
-void ntt_sigma_inverse_map(u32 logN, std::vector<u32> &map);
+void ntt_sigma_inverse_map(u32 logN, u32 s0, std::vector<u32> &map);  // s0 = ~0u: identity
 // sigma: keep the EVALUATION side in the register-blocked kernel's lane order (internal arrays only; ignored,
 // i.e. standard order, when that kernel does not apply -- ntt_sigma_inverse_map is then the identity)
+// folded: the outermost stage is NOT done here (the caller's neighbouring kernels apply it, kernels_pie.hip
+// "Outer-stage folding"); the limb is transformed as two independent half-size slices.  Requires pl.twc_fold.
 void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, hipStream_t st,
-                bool sigma = false);
+                bool sigma = false, bool folded = false);
 
 // Stage A: acc[b][K][2][L][N] = sum_j idx[h][j] (.) db[h][beta][j] + minus    (BatchedFHEHIPPIE.cpp:101-116)
 // small_moduli: every RNS modulus is < 2^60 (enables the v_mad_u64_u32 column-accumulator kernel)
 void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
                     const u64 *db, u64 *acc, hipStream_t st, bool small_moduli);
 
+// (process-wide switch, set from the context before its launches: all Q and P moduli are < 2^60, which lets the
+// base-conversion kernels use the carry-free v_mad_u64_u32 column accumulators)
+void set_small_moduli(bool v);
+
 // Base conversions, COEFFICIENT format.  Polynomial (o, c), o < n_outer, c < 2,
 // is read at in + o*in_stride_outer + c*in_stride_inner ([L][N] limbs) and written to
 // out + ((o*out_polys + out_slot + c)*M)*N ([M][N] limbs).
 void launch_expand_q_to_qp(const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t in_stride_outer,
-                           size_t in_stride_inner, u32 n_outer, u64 *out, u32 out_polys, u32 out_slot, hipStream_t st);
+                           size_t in_stride_inner, u32 n_outer, u64 *out, u32 out_polys, u32 out_slot, hipStream_t st,
+                           bool fold = false);
 void launch_scale_pq_expand(const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t in_stride_outer,
-                            size_t in_stride_inner, u32 n_outer, u64 *out, u32 out_polys, u32 out_slot, hipStream_t st);
+                            size_t in_stride_inner, u32 n_outer, u64 *out, u32 out_polys, u32 out_slot, hipStream_t st,
+                            bool fold = false);
 // e[nb][4][M][N] (a0 a1 b0 b1, EVALUATION) -> d[nb][3][M][N]
 void launch_tensor(const DevConsts *dc, u32 N, u32 M, const u64 *e, u64 *d, u32 nb, hipStream_t st);
 // d[nb][3][M][N] (COEFFICIENT) -> components 0,1 to out01 + bin*stride01 + c*L*N, component 2 to out2 + bin*stride2
+// fold: the outermost NTT stage of the neighbouring transforms is applied here (see kernels_pie.hip, "Outer-stage
+// folding"); fold_comp2: component 2 also feeds a forward transform directly (3-component output)
 void launch_scale_round(const DevConsts *dc, u32 N, u32 L, const u64 *d, u32 nb, u64 *out01, size_t stride01, u64 *out2,
-                        size_t stride2, hipStream_t st);
+                        size_t stride2, hipStream_t st, bool fold = false, bool fold_comp2 = false);
 // BV digits: d2c at d2 + bin*stride2 ([L][N], COEFFICIENT) -> dig[nb][L(i)][L(j)][N] (centred lift of residue i into q_j)
-void launch_digits(const DevConsts *dc, u32 N, u32 L, const u64 *d2, size_t stride2, u32 nb, u64 *dig, hipStream_t st);
+void launch_digits(const DevConsts *dc, u32 N, u32 L, const u64 *d2, size_t stride2, u32 nb, u64 *dig, hipStream_t st,
+                   bool fold = false);
 // out[bin][c][j] = (d01[bin][c][j] + sum_i dig[bin][i][j] (.) key[i][c][j]) (.) mask[bin][j]   (mask may be null)
 // out_map (may be null): coefficient n of the result is written to position out_map[n] (lane order -> standard)
 void launch_relin_mac(const DevConsts *dc, u32 N, u32 L, const u64 *d01, size_t stride01, const u64 *dig, const u64 *key,

@@ -140,9 +140,15 @@ u32 ntt_fast_s0(u32 logN)
     return (logN - s0 >= 12 && logN - s0 <= 14) ? s0 : ~0u;
 }
 
-void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, hipStream_t st, bool sigma)
+void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, hipStream_t st, bool sigma,
+                bool folded)
 {
     if (!nlimbs) return;
+    if (folded) {  // two half-size slices per limb, outer stage done by the neighbouring kernels
+        (void)launch_ntt_fast(pl.twp, pl.twc_fold, pl.dc, pl.N, pl.logN, 1, data, nlimbs, mod_base, mod_count, inverse, sigma,
+                              pl.num_cus, st);
+        return;
+    }
     NttArgs a;
     a.data = data;
     a.tables = pl.tables;

@@ -529,11 +529,10 @@ void build_twc_table(const u64 *nat, u32 logN, u32 s0, std::vector<u64> &out)
 
 // lane-order position p (within the limb) -> standard position; identity when the register-blocked kernel
 // does not apply to this ring dimension
-void ntt_sigma_inverse_map(u32 logN, std::vector<u32> &map)
+void ntt_sigma_inverse_map(u32 logN, u32 s0, std::vector<u32> &map)
 {
     const u32 N = 1u << logN;
     map.resize(N);
-    const u32 s0 = ntt_fast_s0(logN);
     if (s0 == ~0u) {
         for (u32 p = 0; p < N; p++) map[p] = p;
         return;

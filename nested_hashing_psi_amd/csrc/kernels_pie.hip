@@ -200,55 +200,82 @@ void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, cons
 // ---------------------------------------------------------------------------------------------
 // centred CRT lift of y_i-weighted residues from a source basis into target modulus `tm`:
 //   sum_i y_i * hat[i] - v * prodmod
-template <u32 MAXS>
-__device__ __forceinline__ u64 crt_out(const u64 *y, u32 ns, const u64 *hat, u32 hat_stride, u64 v, u64 prodmod,
-                                       const Mod &tm)
+// sum_i y[i] * c[i * stride] as a 128-bit integer.  MAD: carry-free column accumulators on v_mad_u64_u32
+// (madasm.h; needs all operands < 2^60 and NS <= 8), otherwise 64x64->128 multiplies.
+template <u32 NS, bool MAD>
+__device__ __forceinline__ U128 dot128(const u64 *y, const u64 *c, u32 stride)
 {
+    if (MAD) {
+        ColAcc a = {0, 0, 0};
+#pragma unroll
+        for (u32 i = 0; i < NS; i++) colacc_mac(a, split30(y[i]), split30(c[(size_t)i * stride]));
+        return colacc_value(a);
+    }
     U128 acc = {0, 0};
-    for (u32 i = 0; i < ns; i++) mac128(acc, y[i], hat[(size_t)i * hat_stride]);
+#pragma unroll
+    for (u32 i = 0; i < NS; i++) mac128(acc, y[i], c[(size_t)i * stride]);
+    return acc;
+}
+
+template <u32 NS, bool MAD>
+__device__ __forceinline__ u64 crt_out(const u64 *y, const u64 *hat, u32 hat_stride, u64 v, u64 prodmod, const Mod &tm)
+{
+    U128 acc = dot128<NS, MAD>(y, hat, hat_stride);
     mac128(acc, v, tm.q - prodmod);  // - v * prodmod (mod tm); v <= ns: one Barrett reduction for the whole sum
     return reduce128(acc, tm);
 }
 
-__global__ void __launch_bounds__(TPB) expand_q_to_qp_kernel(const DevConsts *dc, u32 N, u32 L, const u64 *__restrict__ in,
-                                                             size_t so, size_t si, u64 *__restrict__ out, u32 out_polys,
-                                                             u32 out_slot)
+// Outer-stage folding.  For N >= 2^14 the transforms next to these kernels run as two half-size slices per limb
+// (two workgroups per CU, finer scheduling granularity) and the outermost radix-2 stage moves here, where both
+// coefficients n and n + N/2 of every limb pass through registers anyway:
+//   load side  (input comes from an inverse transform):  (u, v) -> ((u + v) N^-1, (u - v) psi^{-N/2} N^-1)
+//   store side (output goes to a forward transform):     (u, v) -> (u + v psi^{N/2}, u - v psi^{N/2})
+__device__ __forceinline__ void fold_load(const DevConsts *dc, u32 a, u64 u, u64 v, u64 &x0, u64 &x1)
 {
-    const u32 n = blockIdx.x * TPB + threadIdx.x;
-    if (n >= N) return;
-    const u32 o = blockIdx.y >> 1, c = blockIdx.y & 1;
-    const u32 M = 2 * L + 1, Lp = L + 1;
-    const u64 *pin = in + (size_t)o * so + (size_t)c * si + n;
-    u64 *pout = out + ((size_t)(o * out_polys + out_slot + c) * M) * N + n;
-    u64 y[MAX_L];
+    const u64 q = dc->mod[a].q;
+    x0 = mul_shoup(addmod(u, v, q), dc->fold_ia[a], dc->fold_ia_sh[a], q);
+    x1 = mul_shoup(submod(u, v, q), dc->fold_ib[a], dc->fold_ib_sh[a], q);
+}
+__device__ __forceinline__ void fold_store(const DevConsts *dc, u32 a, u64 u, u64 v, u64 &y0, u64 &y1)
+{
+    const u64 q = dc->mod[a].q;
+    const u64 t = mul_shoup(v, dc->fold_w[a], dc->fold_w_sh[a], q);
+    y0 = addmod(u, t, q);
+    y1 = submod(u, t, q);
+}
+
+// The RNS width L is a template parameter: with run-time trip counts hipcc indexes the per-coefficient residue
+// arrays dynamically and spills them to scratch.
+// x[L] (mod Q) -> out[M]: Q limbs copied, P limbs = centred CRT lift
+template <u32 L, bool MAD>
+__device__ __forceinline__ void expand_core(const DevConsts *dc, const u64 *x, u64 *out)
+{
+    constexpr u32 Lp = L + 1;
+    u64 y[L];
     u64 fsum = 0;
+#pragma unroll
     for (u32 i = 0; i < L; i++) {
-        const u64 x = pin[(size_t)i * N];
-        pout[(size_t)i * N] = x;
-        y[i] = mul_shoup(x, dc->qhat_inv[i], dc->qhat_inv_sh[i], dc->mod[i].q);
+        out[i] = x[i];
+        y[i] = mul_shoup(x[i], dc->qhat_inv[i], dc->qhat_inv_sh[i], dc->mod[i].q);
         fsum += fixfrac(y[i], dc->mod[i]);
     }
     const u64 v = (fsum + FIX_HALF) >> 60;
-    for (u32 j = 0; j < Lp; j++)
-        pout[(size_t)(L + j) * N] = crt_out<MAX_L>(y, L, &dc->qhat_modp[0][j], 8, v, dc->Q_modp[j], dc->mod[L + j]);
+#pragma unroll
+    for (u32 j = 0; j < Lp; j++) out[L + j] = crt_out<L, MAD>(y, &dc->qhat_modp[0][j], 8, v, dc->Q_modp[j], dc->mod[L + j]);
 }
 
-__global__ void __launch_bounds__(TPB) scale_pq_expand_kernel(const DevConsts *dc, u32 N, u32 L,
-                                                              const u64 *__restrict__ in, size_t so, size_t si,
-                                                              u64 *__restrict__ out, u32 out_polys, u32 out_slot)
+// x[L] (mod Q) -> out[M]: P limbs = round(P x / Q), Q limbs = centred CRT lift of that
+template <u32 L, bool MAD>
+__device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 *x, u64 *out)
 {
-    const u32 n = blockIdx.x * TPB + threadIdx.x;
-    if (n >= N) return;
-    const u32 o = blockIdx.y >> 1, c = blockIdx.y & 1;
-    const u32 M = 2 * L + 1, Lp = L + 1;
-    const u64 *pin = in + (size_t)o * so + (size_t)c * si + n;
-    u64 *pout = out + ((size_t)(o * out_polys + out_slot + c) * M) * N + n;
-    u64 y[MAX_L];
+    constexpr u32 Lp = L + 1;
+    u64 y[L];
     u64 fsum = 0;
     U128 itot = {0, 0};
+#pragma unroll
     for (u32 i = 0; i < L; i++) {
         const Mod &mi = dc->mod[i];
-        y[i] = mul_shoup(pin[(size_t)i * N], dc->qhat_inv[i], dc->qhat_inv_sh[i], mi.q);
+        y[i] = mul_shoup(x[i], dc->qhat_inv[i], dc->qhat_inv_sh[i], mi.q);
         // y_i P / q_i = y_i floor(P/q_i) + floor(y_i w_i / q_i) + (y_i w_i mod q_i) / q_i
         u64 fl, z;
         divmod_shoup(y[i], dc->P_modq[i], dc->P_modq_sh[i], mi.q, fl, z);
@@ -256,41 +283,98 @@ __global__ void __launch_bounds__(TPB) scale_pq_expand_kernel(const DevConsts *d
         fsum += fixfrac(z, mi);
     }
     add128(itot, U128{(fsum + FIX_HALF) >> 60, 0});
-    u64 yp[MAX_L + 1];
+    u64 yp[Lp];
     u64 fs2 = 0;
+#pragma unroll
     for (u32 j = 0; j < Lp; j++) {
         const Mod &pj = dc->mod[L + j];
-        U128 acc = {0, 0};
-        for (u32 i = 0; i < L; i++) mac128(acc, y[i], dc->PI_modp[i][j]);
+        U128 acc = dot128<L, MAD>(y, &dc->PI_modp[0][j], 8);
         add128(acc, itot);
         const u64 r = reduce128(acc, pj);
-        pout[(size_t)(L + j) * N] = r;
+        out[L + j] = r;
         yp[j] = mul_shoup(r, dc->phat_inv[j], dc->phat_inv_sh[j], pj.q);
         fs2 += fixfrac(yp[j], pj);
     }
     const u64 v = (fs2 + FIX_HALF) >> 60;
-    for (u32 i = 0; i < L; i++)
-        pout[(size_t)i * N] = crt_out<MAX_L + 1>(yp, Lp, &dc->phat_modq[0][i], 8, v, dc->P_modq[i], dc->mod[i]);
+#pragma unroll
+    for (u32 i = 0; i < L; i++) out[i] = crt_out<Lp, MAD>(yp, &dc->phat_modq[0][i], 8, v, dc->P_modq[i], dc->mod[i]);
 }
 
-static void launch_expand_common(bool scale, const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t so, size_t si,
+template <bool SCALE, bool FOLD, u32 L, bool MAD>
+__global__ void __launch_bounds__(TPB) expand_kernel(const DevConsts *__restrict__ dc, u32 N, const u64 *__restrict__ in,
+                                                     size_t so, size_t si, u64 *__restrict__ out, u32 out_polys, u32 out_slot)
+{
+    const u32 n = blockIdx.x * TPB + threadIdx.x;
+    const u32 H = N / 2;
+    if (n >= (FOLD ? H : N)) return;
+    const u32 o = blockIdx.y >> 1, c = blockIdx.y & 1;
+    constexpr u32 M = 2 * L + 1;
+    const u64 *pin = in + (size_t)o * so + (size_t)c * si + n;
+    u64 *pout = out + ((size_t)(o * out_polys + out_slot + c) * M) * N + n;
+    constexpr int NP = FOLD ? 2 : 1;
+    u64 x[NP][L], y[NP][M];
+#pragma unroll
+    for (u32 i = 0; i < L; i++) {
+        if (FOLD)
+            fold_load(dc, i, pin[(size_t)i * N], pin[(size_t)i * N + H], x[0][i], x[NP - 1][i]);
+        else
+            x[0][i] = pin[(size_t)i * N];
+    }
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        if (SCALE)
+            scale_pq_core<L, MAD>(dc, x[p], y[p]);
+        else
+            expand_core<L, MAD>(dc, x[p], y[p]);
+    }
+#pragma unroll
+    for (u32 a = 0; a < M; a++) {
+        if (FOLD) {
+            u64 y0, y1;
+            fold_store(dc, a, y[0][a], y[NP - 1][a], y0, y1);
+            pout[(size_t)a * N] = y0;
+            pout[(size_t)a * N + H] = y1;
+        } else {
+            pout[(size_t)a * N] = y[0][a];
+        }
+    }
+}
+
+static bool g_small_moduli = false;  // set per launch by the callers' context (all Q, P moduli < 2^60)
+void set_small_moduli(bool v) { g_small_moduli = v; }
+
+static void launch_expand_common(bool scale, bool fold, const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t so, size_t si,
                                  u32 n_outer, u64 *out, u32 out_polys, u32 out_slot, hipStream_t st)
 {
-    dim3 grid((N + TPB - 1) / TPB, n_outer * 2);
-    if (scale)
-        hipLaunchKernelGGL(scale_pq_expand_kernel, grid, dim3(TPB), 0, st, dc, N, L, in, so, si, out, out_polys, out_slot);
-    else
-        hipLaunchKernelGGL(expand_q_to_qp_kernel, grid, dim3(TPB), 0, st, dc, N, L, in, so, si, out, out_polys, out_slot);
+    dim3 grid(((fold ? N / 2 : N) + TPB - 1) / TPB, n_outer * 2);
+#define EX(S_, F_, L_)                                                                                                     \
+    do {                                                                                                                   \
+        if (g_small_moduli)                                                                                                \
+            hipLaunchKernelGGL((expand_kernel<S_, F_, L_, true>), grid, dim3(TPB), 0, st, dc, N, in, so, si, out, out_polys, out_slot); \
+        else                                                                                                               \
+            hipLaunchKernelGGL((expand_kernel<S_, F_, L_, false>), grid, dim3(TPB), 0, st, dc, N, in, so, si, out, out_polys, out_slot); \
+    } while (0)
+#define EXL(L_)                                                   \
+    case L_:                                                      \
+        if (scale) {                                              \
+            if (fold) EX(true, true, L_); else EX(true, false, L_);   \
+        } else {                                                  \
+            if (fold) EX(false, true, L_); else EX(false, false, L_); \
+        }                                                         \
+        break;
+    switch (L) { EXL(1) EXL(2) EXL(3) EXL(4) EXL(5) EXL(6) EXL(7) }
+#undef EXL
+#undef EX
 }
 void launch_expand_q_to_qp(const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t so, size_t si, u32 n_outer, u64 *out,
-                           u32 out_polys, u32 out_slot, hipStream_t st)
+                           u32 out_polys, u32 out_slot, hipStream_t st, bool fold)
 {
-    launch_expand_common(false, dc, N, L, in, so, si, n_outer, out, out_polys, out_slot, st);
+    launch_expand_common(false, fold, dc, N, L, in, so, si, n_outer, out, out_polys, out_slot, st);
 }
 void launch_scale_pq_expand(const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t so, size_t si, u32 n_outer, u64 *out,
-                            u32 out_polys, u32 out_slot, hipStream_t st)
+                            u32 out_polys, u32 out_slot, hipStream_t st, bool fold)
 {
-    launch_expand_common(true, dc, N, L, in, so, si, n_outer, out, out_polys, out_slot, st);
+    launch_expand_common(true, fold, dc, N, L, in, so, si, n_outer, out, out_polys, out_slot, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -322,63 +406,129 @@ void launch_tensor(const DevConsts *dc, u32 N, u32 M, const u64 *e, u64 *d, u32 
 // ---------------------------------------------------------------------------------------------
 // Scale-and-round by t/P from QP into Q (row A6)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(TPB) scale_round_kernel(const DevConsts *dc, u32 N, u32 L, const u64 *__restrict__ d,
-                                                          u64 *__restrict__ out01, size_t stride01,
-                                                          u64 *__restrict__ out2, size_t stride2)
+// d[M] (mod QP) -> out[L]: round(t d / P) mod Q
+template <u32 L, bool MAD>
+__device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 *d, u64 *out)
 {
-    const u32 n = blockIdx.x * TPB + threadIdx.x;
-    if (n >= N) return;
-    const u32 comp = blockIdx.y, bin = blockIdx.z;
-    const u32 M = 2 * L + 1, Lp = L + 1;
-    const u64 *pin = d + ((size_t)(bin * 3 + comp) * M) * N + n;
-    u64 *pout = comp < 2 ? out01 + (size_t)bin * stride01 + (size_t)comp * L * N + n : out2 + (size_t)bin * stride2 + n;
-    u64 yp[MAX_L + 1];
+    constexpr u32 Lp = L + 1;
+    u64 yp[Lp];
     u64 fsum = 0;
     U128 itot = {0, 0};
+#pragma unroll
     for (u32 j = 0; j < Lp; j++) {
         const Mod &pj = dc->mod[L + j];
-        yp[j] = mul_shoup(pin[(size_t)(L + j) * N], dc->qp_hat_inv[L + j], dc->qp_hat_inv_sh[L + j], pj.q);
+        yp[j] = mul_shoup(d[L + j], dc->qp_hat_inv[L + j], dc->qp_hat_inv_sh[L + j], pj.q);
         u64 fl, z;
         divmod_shoup(yp[j], dc->tQ_modp[j], dc->tQ_modp_sh[j], pj.q, fl, z);
         add128(itot, U128{fl, 0});
         fsum += fixfrac(z, pj);
     }
     add128(itot, U128{(fsum + FIX_HALF) >> 60, 0});
+#pragma unroll
     for (u32 k = 0; k < L; k++) {
         const Mod &qk = dc->mod[k];
-        U128 acc = mul128(pin[(size_t)k * N], dc->tPinv_modq[k]);
-        for (u32 j = 0; j < Lp; j++) mac128(acc, yp[j], dc->tQF_modq[j][k]);
+        U128 acc = dot128<Lp, MAD>(yp, &dc->tQF_modq[0][k], 8);
+        mac128(acc, d[k], dc->tPinv_modq[k]);
         add128(acc, itot);
-        pout[(size_t)k * N] = reduce128(acc, qk);
+        out[k] = reduce128(acc, qk);
+    }
+}
+
+// FOLD: inverse outer stage on load; forward outer stage on the store of components 0 and 1 (they go to a
+// forward transform); component 2 is stored as plain coefficients (the digit kernel folds it per target modulus)
+template <bool FOLD, u32 L, bool MAD>
+__global__ void __launch_bounds__(TPB) scale_round_kernel(const DevConsts *__restrict__ dc, u32 N, const u64 *__restrict__ d,
+                                                          u64 *__restrict__ out01, size_t stride01,
+                                                          u64 *__restrict__ out2, size_t stride2, u32 fold_comp2)
+{
+    const u32 n = blockIdx.x * TPB + threadIdx.x;
+    const u32 H = N / 2;
+    if (n >= (FOLD ? H : N)) return;
+    const u32 comp = blockIdx.y, bin = blockIdx.z;
+    constexpr u32 M = 2 * L + 1;
+    const u64 *pin = d + ((size_t)(bin * 3 + comp) * M) * N + n;
+    u64 *pout = comp < 2 ? out01 + (size_t)bin * stride01 + (size_t)comp * L * N + n : out2 + (size_t)bin * stride2 + n;
+    constexpr int NP = FOLD ? 2 : 1;
+    u64 x[NP][M], y[NP][L];
+#pragma unroll
+    for (u32 a = 0; a < M; a++) {
+        if (FOLD)
+            fold_load(dc, a, pin[(size_t)a * N], pin[(size_t)a * N + H], x[0][a], x[NP - 1][a]);
+        else
+            x[0][a] = pin[(size_t)a * N];
+    }
+#pragma unroll
+    for (int p = 0; p < NP; p++) scale_round_core<L, MAD>(dc, x[p], y[p]);
+#pragma unroll
+    for (u32 k = 0; k < L; k++) {
+        if (FOLD) {
+            u64 y0 = y[0][k], y1 = y[NP - 1][k];
+            if (comp < 2 || fold_comp2) fold_store(dc, k, y[0][k], y[NP - 1][k], y0, y1);
+            pout[(size_t)k * N] = y0;
+            pout[(size_t)k * N + H] = y1;
+        } else {
+            pout[(size_t)k * N] = y[0][k];
+        }
     }
 }
 void launch_scale_round(const DevConsts *dc, u32 N, u32 L, const u64 *d, u32 nb, u64 *out01, size_t stride01, u64 *out2,
-                        size_t stride2, hipStream_t st)
+                        size_t stride2, hipStream_t st, bool fold, bool fold_comp2)
 {
-    dim3 grid((N + TPB - 1) / TPB, 3, nb);
-    hipLaunchKernelGGL(scale_round_kernel, grid, dim3(TPB), 0, st, dc, N, L, d, out01, stride01, out2, stride2);
+    dim3 grid(((fold ? N / 2 : N) + TPB - 1) / TPB, 3, nb);
+#define SRL(L_)                                                                                                              \
+    case L_:                                                                                                                 \
+        if (fold && g_small_moduli)                                                                                          \
+            hipLaunchKernelGGL((scale_round_kernel<true, L_, true>), grid, dim3(TPB), 0, st, dc, N, d, out01, stride01, out2, stride2, \
+                               fold_comp2 ? 1u : 0u);                                                                        \
+        else if (fold)                                                                                                       \
+            hipLaunchKernelGGL((scale_round_kernel<true, L_, false>), grid, dim3(TPB), 0, st, dc, N, d, out01, stride01, out2, stride2, \
+                               fold_comp2 ? 1u : 0u);                                                                        \
+        else if (g_small_moduli)                                                                                             \
+            hipLaunchKernelGGL((scale_round_kernel<false, L_, true>), grid, dim3(TPB), 0, st, dc, N, d, out01, stride01, out2, stride2, 0u); \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((scale_round_kernel<false, L_, false>), grid, dim3(TPB), 0, st, dc, N, d, out01, stride01, out2, stride2, 0u); \
+        break;
+    switch (L) { SRL(1) SRL(2) SRL(3) SRL(4) SRL(5) SRL(6) SRL(7) }
+#undef SRL
 }
 
 // ---------------------------------------------------------------------------------------------
 // BV relinearisation (row A7): digit decomposition and key-switch accumulation
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(TPB) digits_kernel(const DevConsts *dc, u32 N, u32 L, const u64 *__restrict__ d2,
-                                                     size_t stride2, u64 *__restrict__ dig)
+__device__ __forceinline__ u64 digit_lift(const DevConsts *dc, u32 i, u32 j, u64 v)
 {
-    const u32 n = blockIdx.x * TPB + threadIdx.x;
-    if (n >= N) return;
-    const u32 i = blockIdx.y / L, j = blockIdx.y % L, bin = blockIdx.z;
-    const u64 v = d2[(size_t)bin * stride2 + (size_t)i * N + n];
     const Mod &mj = dc->mod[j];
     const u64 qi = dc->mod[i].q;
     u64 r = barrett128(0, v, mj);
     if (v > qi / 2) r = submod(r, dc->qi_modqj[i][j], mj.q);  // centred lift of the residue mod q_i
-    dig[(((size_t)bin * L + i) * L + j) * N + n] = r;
+    return r;
 }
-void launch_digits(const DevConsts *dc, u32 N, u32 L, const u64 *d2, size_t stride2, u32 nb, u64 *dig, hipStream_t st)
+template <bool FOLD>
+__global__ void __launch_bounds__(TPB) digits_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, const u64 *__restrict__ d2,
+                                                     size_t stride2, u64 *__restrict__ dig)
 {
-    dim3 grid((N + TPB - 1) / TPB, L * L, nb);
-    hipLaunchKernelGGL(digits_kernel, grid, dim3(TPB), 0, st, dc, N, L, d2, stride2, dig);
+    const u32 n = blockIdx.x * TPB + threadIdx.x;
+    const u32 H = N / 2;
+    if (n >= (FOLD ? H : N)) return;
+    const u32 i = blockIdx.y / L, j = blockIdx.y % L, bin = blockIdx.z;
+    const u64 *pin = d2 + (size_t)bin * stride2 + (size_t)i * N + n;
+    u64 *pout = dig + (((size_t)bin * L + i) * L + j) * N + n;
+    if (FOLD) {
+        u64 y0, y1;
+        fold_store(dc, j, digit_lift(dc, i, j, pin[0]), digit_lift(dc, i, j, pin[H]), y0, y1);
+        pout[0] = y0;
+        pout[H] = y1;
+    } else {
+        pout[0] = digit_lift(dc, i, j, pin[0]);
+    }
+}
+void launch_digits(const DevConsts *dc, u32 N, u32 L, const u64 *d2, size_t stride2, u32 nb, u64 *dig, hipStream_t st, bool fold)
+{
+    dim3 grid(((fold ? N / 2 : N) + TPB - 1) / TPB, L * L, nb);
+    if (fold)
+        hipLaunchKernelGGL(digits_kernel<true>, grid, dim3(TPB), 0, st, dc, N, L, d2, stride2, dig);
+    else
+        hipLaunchKernelGGL(digits_kernel<false>, grid, dim3(TPB), 0, st, dc, N, L, d2, stride2, dig);
 }
 
 __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *dc, u32 N, u32 L, const u64 *__restrict__ d01,

@@ -170,6 +170,12 @@ std::string HostParams::init(u32 N_, u32 L_, u64 t_, const u64 *q, const u64 *p)
             pw = mm(pw, psi[a], m);
             ipw = mm(ipw, ipsi, m);
         }
+        dc.fold_w[a] = tw[a][1];
+        dc.fold_w_sh[a] = tw_sh[a][1];
+        dc.fold_ia[a] = dc.mod[a].n_inv;
+        dc.fold_ia_sh[a] = dc.mod[a].n_inv_sh;
+        dc.fold_ib[a] = mm(itw[a][1], dc.mod[a].n_inv, m);
+        dc.fold_ib_sh[a] = shoup(dc.fold_ib[a], m);
     }
 
     // slot i <-> evaluation point psi^(5^i), slot N/2+i <-> psi^(-5^i); EVALUATION position p

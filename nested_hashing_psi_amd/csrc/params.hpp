@@ -40,6 +40,10 @@ struct DevConsts {
     u64 tQ_modp_sh[8];
     u64 tQF_modq[8][8];       // [j][k]  [floor(tQ/p_j)]_{q_k}
     u64 qi_modqj[8][8];       // [i][j]  q_i mod q_j  (centred digit lift of the BV key switch)
+    // outermost NTT stage folded into the neighbouring coefficient-wise kernels (kernels_pie.hip):
+    u64 fold_w[MAX_M + 1], fold_w_sh[MAX_M + 1];    // forward: psi^{N/2} (twiddle of the stage with one group)
+    u64 fold_ia[MAX_M + 1], fold_ia_sh[MAX_M + 1];  // inverse: N^-1            (sum branch)
+    u64 fold_ib[MAX_M + 1], fold_ib_sh[MAX_M + 1];  // inverse: psi^{-N/2} N^-1 (difference branch)
     u32 N, logN, L, M;
 };
 

@@ -62,6 +62,8 @@ struct piehip_ctx {
     u64 *d_tables = nullptr;  // [(M+1)][4][N]
     u64 *d_twp = nullptr;     // [(M+1)][2][N][2] interleaved {w, w_shoup}
     u64 *d_twc = nullptr;     // pass-C kernel-order copy of the same pairs
+    u64 *d_twc_fold = nullptr;  // ... for the folded configuration (two half-size slices per limb)
+    bool fold_on = false;     // outermost NTT stage folded into the coefficient-wise kernels (N >= 2^14)
     u32 *d_inv_pos = nullptr; // EVALUATION position -> slot
     u32 *d_sigma_inv = nullptr;  // lane-order position -> standard position (identity for small rings)
     bool small_moduli = false;   // all Q and P moduli < 2^60
@@ -163,25 +165,28 @@ static void ws_free(MulWs &w)
 }
 
 // ---- schedule pieces ----------------------------------------------------------------------------
-static void ntt(piehip_ctx *h, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inv, bool sigma = false)
+// sigma: lane order on the EVALUATION side; fold: outer stage applied by the neighbouring kernels (both only
+// take effect when the context supports them; callers pass the same flags to those neighbours)
+static void ntt(piehip_ctx *h, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inv, bool sigma = false, bool fold = false)
 {
     ProfScope ps(h, inv ? PIEHIP_K_NTT_INV : PIEHIP_K_NTT_FWD, 16.0 * h->hp.N * nlimbs);
-    launch_ntt(h->plan, data, nlimbs, mod_base, mod_count, inv, h->stream, sigma && h->sigma_on);
+    launch_ntt(h->plan, data, nlimbs, mod_base, mod_count, inv, h->stream, sigma && h->sigma_on, fold && h->fold_on);
 }
 
 // BV key switch of the COEFFICIENT-format polynomials at w.d2c with `key`, added to the EVALUATION
 // ciphertexts at w.d01, optionally multiplied by mask plaintexts: out[nb][2][L][N]
 // sigma: w.d01 and the digits are in lane order, key/mask are lane-ordered copies, out is written in standard order
-static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, const u64 *mask, u64 *out, bool sigma = false)
+static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, const u64 *mask, u64 *out, bool sigma = false,
+                              bool fold = false)
 {
     const u32 N = h->hp.N, L = h->hp.L;
     const size_t LN = h->LN();
     const double W = 8.0 * N;
     {
         ProfScope ps(h, PIEHIP_K_DIGITS, W * nb * (L + (double)L * L));
-        launch_digits(h->d_dc, N, L, w.d2c, LN, nb, w.dig, h->stream);
+        launch_digits(h->d_dc, N, L, w.d2c, LN, nb, w.dig, h->stream, fold && h->fold_on);
     }
-    ntt(h, w.dig, nb * L * L, 0, L, false, sigma);
+    ntt(h, w.dig, nb * L * L, 0, L, false, sigma, fold);
     {
         ProfScope ps(h, PIEHIP_K_RELIN, W * (nb * ((double)L * L + 2 * L + 2 * L + (mask ? L : 0)) + 2.0 * L * L));
         launch_relin_mac(h->d_dc, N, L, w.d01, 2 * LN, w.dig, key, mask, out, nb, h->stream,
@@ -189,7 +194,8 @@ static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, c
     }
 }
 
-// One batched EvalMult(ct,ct) (BatchedFHEHIPPIE.cpp:123): operands in COEFFICIENT format,
+// One batched EvalMult(ct,ct) (BatchedFHEHIPPIE.cpp:123): operands in COEFFICIENT format (produced by
+// ntt(.., inverse, sigma = false, fold = true): with folding on, their outermost inverse stage is applied here),
 // X polynomial (o,c) at x + o*sx + c*LN, Y likewise.  relin: out[nb][2][L][N] (times mask if given);
 // otherwise out[nb][3][L][N] holds the EVALUATION-format tensor result.
 static void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const u64 *y, size_t sy, u32 nb, bool relin,
@@ -198,31 +204,32 @@ static void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const 
     const u32 N = h->hp.N, L = h->hp.L, M = h->hp.M;
     const size_t LN = h->LN();
     const double W = 8.0 * N;
+    set_small_moduli(h->small_moduli);
     {
         ProfScope ps(h, PIEHIP_K_EXPAND, W * nb * (4.0 * L + 4.0 * M));
-        launch_expand_q_to_qp(h->d_dc, N, L, x, sx, LN, nb, w.eqp, 4, 0, h->stream);
-        launch_scale_pq_expand(h->d_dc, N, L, y, sy, LN, nb, w.eqp, 4, 2, h->stream);
+        launch_expand_q_to_qp(h->d_dc, N, L, x, sx, LN, nb, w.eqp, 4, 0, h->stream, h->fold_on);
+        launch_scale_pq_expand(h->d_dc, N, L, y, sy, LN, nb, w.eqp, 4, 2, h->stream, h->fold_on);
     }
     // the QP operands and the tensor result never leave the library: lane order, no LDS transposes
-    ntt(h, w.eqp, nb * 4 * M, 0, M, false, true);
+    ntt(h, w.eqp, nb * 4 * M, 0, M, false, true, true);
     {
         ProfScope ps(h, PIEHIP_K_TENSOR, W * nb * 7.0 * M);
         launch_tensor(h->d_dc, N, M, w.eqp, w.dqp, nb, h->stream);
     }
-    ntt(h, w.dqp, nb * 3 * M, 0, M, true, true);
+    ntt(h, w.dqp, nb * 3 * M, 0, M, true, true, true);
     if (relin) {
         {
             ProfScope ps(h, PIEHIP_K_SCALE, W * nb * (3.0 * M + 3.0 * L));
-            launch_scale_round(h->d_dc, N, L, w.dqp, nb, w.d01, 2 * LN, w.d2c, LN, h->stream);
+            launch_scale_round(h->d_dc, N, L, w.dqp, nb, w.d01, 2 * LN, w.d2c, LN, h->stream, h->fold_on, false);
         }
-        ntt(h, w.d01, nb * 2 * L, 0, L, false, true);
-        enqueue_keyswitch(h, w, nb, h->sigma_on ? h->d_evk_sigma : h->d_evk, mask, out, true);
+        ntt(h, w.d01, nb * 2 * L, 0, L, false, true, true);
+        enqueue_keyswitch(h, w, nb, h->sigma_on ? h->d_evk_sigma : h->d_evk, mask, out, true, true);
     } else {
         {
             ProfScope ps(h, PIEHIP_K_SCALE, W * nb * (3.0 * M + 3.0 * L));
-            launch_scale_round(h->d_dc, N, L, w.dqp, nb, out, 3 * LN, out + 2 * LN, 3 * LN, h->stream);
+            launch_scale_round(h->d_dc, N, L, w.dqp, nb, out, 3 * LN, out + 2 * LN, 3 * LN, h->stream, h->fold_on, true);
         }
-        ntt(h, out, nb * 3 * L, 0, L, false);
+        ntt(h, out, nb * 3 * L, 0, L, false, false, true);
     }
 }
 
@@ -315,6 +322,17 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
                 }
             CHK_(hipMalloc((void **)&h->d_twc, all.size() * sizeof(u64)));
             CHK_(hipMemcpy(h->d_twc, all.data(), all.size() * sizeof(u64), hipMemcpyHostToDevice));
+            if (h->hp.logN >= 14 && h->hp.logN <= 15) {  // folded configuration: slices of N/2
+                all.clear();
+                for (u32 a = 0; a <= M; a++)
+                    for (u32 dir = 0; dir < 2; dir++) {
+                        build_twc_table(&pairs[((size_t)a * 2 + dir) * 2 * N], h->hp.logN, 1, one);
+                        all.insert(all.end(), one.begin(), one.end());
+                    }
+                CHK_(hipMalloc((void **)&h->d_twc_fold, all.size() * sizeof(u64)));
+                CHK_(hipMemcpy(h->d_twc_fold, all.data(), all.size() * sizeof(u64), hipMemcpyHostToDevice));
+                h->fold_on = true;
+            }
         }
     }
     {
@@ -327,7 +345,7 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
     h->plan.tables = h->d_tables;
     {
         std::vector<u32> smap;
-        ntt_sigma_inverse_map(h->hp.logN, smap);
+        ntt_sigma_inverse_map(h->hp.logN, h->d_twc ? (h->fold_on ? 1u : ntt_fast_s0(h->hp.logN)) : ~0u, smap);
         if (hipMalloc((void **)&h->d_sigma_inv, sizeof(u32) * N) != hipSuccess ||
             hipMemcpy(h->d_sigma_inv, smap.data(), sizeof(u32) * N, hipMemcpyHostToDevice) != hipSuccess) {
             piehip_destroy(h);
@@ -340,6 +358,7 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
     }
     h->plan.twp = h->d_twp;
     h->plan.twc = h->d_twc;
+    h->plan.twc_fold = h->d_twc_fold;
     h->plan.force_generic = false;
     {
         hipDeviceProp_t prop;
@@ -372,6 +391,7 @@ int piehip_destroy(piehip_handle h)
     if (h->d_tables) (void)hipFree(h->d_tables);
     if (h->d_twp) (void)hipFree(h->d_twp);
     if (h->d_twc) (void)hipFree(h->d_twc);
+    if (h->d_twc_fold) (void)hipFree(h->d_twc_fold);
     if (h->d_inv_pos) (void)hipFree(h->d_inv_pos);
     if (h->d_sigma_inv) (void)hipFree(h->d_sigma_inv);
     dev_free(&h->d_evk_sigma);
@@ -594,7 +614,7 @@ int piehip_run(piehip_handle h)
         launch_stage_a(h->d_dc, N, L, K, b, E, h->d_idx, h->d_minus, h->d_db, h->d_acc, h->stream, h->small_moduli);
     }
     // every accumulator enters a ct x ct product exactly once: switch them all to COEFFICIENT format
-    ntt(h, h->d_acc, b * K * 2 * L, 0, L, true);
+    ntt(h, h->d_acc, b * K * 2 * L, 0, L, true, false, true);
     // product chain over the inner hash functions (BatchedFHEHIPPIE.cpp:117-124); the mask multiply
     // (:126) is fused into the last key switch
     const u64 *x = h->d_acc;
@@ -604,7 +624,7 @@ int piehip_run(piehip_handle h)
         u64 *dst = last ? h->d_out : h->d_prod;
         enqueue_mul(h, h->ws, x, sx, h->d_acc + (size_t)hf * 2 * LN, (size_t)K * 2 * LN, b, true, last ? (h->sigma_on ? h->d_masks_sigma : h->d_masks) : nullptr, dst);
         if (!last) {
-            ntt(h, h->d_prod, b * 2 * L, 0, L, true);
+            ntt(h, h->d_prod, b * 2 * L, 0, L, true, false, true);
             x = h->d_prod;
             sx = 2 * LN;
         }
@@ -733,7 +753,7 @@ int piehip_eval_mult(piehip_handle h, const uint64_t *x, const uint64_t *y, uint
         ws_free(w);
         return rc;
     }
-    ntt(h, dxy, nct * 4 * L, 0, L, true);
+    ntt(h, dxy, nct * 4 * L, 0, L, true, false, true);
     enqueue_mul(h, w, dxy, 4 * LN, dxy + 2 * LN, 4 * LN, nct, relin != 0, nullptr, dout);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -820,6 +840,7 @@ int piehip_base_convert(piehip_handle h, int which, const uint64_t *in, uint32_t
     const size_t win = (size_t)npoly * (which == 2 ? MN : LN), wout = (size_t)npoly * (which == 2 ? LN : MN);
     TMPGET(din, win);
     TMPGET(dout, wout);
+    set_small_moduli(h->small_moduli);
     HIPCHK(hipMemcpy(din, in, win * sizeof(u64), hipMemcpyHostToDevice));
     if (which == 0)
         launch_expand_q_to_qp(h->d_dc, N, L, din, 2 * LN, LN, npoly / 2, dout, 2, 0, h->stream);
