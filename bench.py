@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--force-collective", action="store_true",
+                    help="rehearsal: run the RCCL gather path even with one rank (launch under torch.distributed.run)")
     args = ap.parse_args()
 
     import torch
@@ -116,7 +118,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or (args.force_collective and "RANK" in os.environ)
+    if use_dist:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -152,25 +155,38 @@ def main():
         op.setIndexDevice(idx.data_ptr())
         op.setMinusCompareElementDevice(minus.data_ptr())
     ct_words = 2 * L * N
-    gathered = None
-    my_out = None
-    if world > 1:
-        # gather buffers allocated once, outside the timed region
+    gathered = my_out = works = None
+    if use_dist:
+        # gather buffers allocated once, outside the timed region; two sets so that the gather of query i
+        # (RCCL's own stream) overlaps run() of query i+1 (a server answers a stream of queries)
         bmax = shard.max_bins(b, world) if args.scaling == "strong" else b_local
-        my_out = torch.zeros((bmax, ct_words), dtype=torch.int64, device=device)
-        gathered = torch.empty((world * bmax, ct_words), dtype=torch.int64, device=device)
+        my_out = [torch.zeros((bmax, ct_words), dtype=torch.int64, device=device) for _ in range(2)]
+        gathered = [torch.empty((world * bmax, ct_words), dtype=torch.int64, device=device) for _ in range(2)]
+        works = [None, None]
+    state = {"i": 0}
 
     def step():
         if op is not None:
             op.run(sync=False)
-        if world > 1:
+        if use_dist:
+            s_ = state["i"] & 1
+            state["i"] += 1
+            if works[s_] is not None:
+                works[s_].wait()                              # buffer set s_ is free again (query i-2 gathered)
             if op is not None:
-                op.copyResultsToDevice(my_out.data_ptr())   # same stream as run(): ordered after it
+                op.copyResultsToDevice(my_out[s_].data_ptr())   # same stream as run(): ordered after it
             # the path's only collective: RCCL all-gather of the result ciphertexts
-            dist.all_gather_into_tensor(gathered, my_out)
+            works[s_] = dist.all_gather_into_tensor(gathered[s_], my_out[s_], async_op=True)
+
+    def drain():
+        if use_dist:
+            for w_ in works:
+                if w_ is not None:
+                    w_.wait()
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize(device)
     if dist:
         dist.barrier()
@@ -178,6 +194,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize(device)
     if dist:
         dist.barrier()
@@ -226,7 +243,7 @@ def main():
                                    % (args.config, N, L, t, cfg["S"].bit_length() - 1, cfg["C"].bit_length() - 1, cfg["k"], cfg["e"], B, K, E,
                                       b_local, b_local * K * E, b_local * (K - 1), b_local),
                        "result_ciphertexts_per_step": b_total, "parallelism": "bins%d" % world,
-                       "collective": "rccl all_gather of results" if world > 1 else "none"},
+                       "collective": "rccl all_gather of results" if use_dist else "none"},
             "mac_per_s": b_total * K * E / (ms_per_step * 1e-3),
             "roofline": roofline, "kernels": kernels,
         }
