@@ -26,7 +26,15 @@ struct NttPlan {
 void build_twc_table(const u64 *nat_pairs, u32 logN, u32 s0, std::vector<u64> &out);
 u32 ntt_fast_s0(u32 logN);  // log2 slices per limb the fast kernel would use, or ~0u if it does not apply
 bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
-                     u32 mod_count, bool inverse, bool sigma, u32 num_cus, hipStream_t st);
+                     u32 mod_count, bool inverse, bool sigma, u32 num_cus, hipStream_t st, const u64 *lift_src = nullptr,
+                     u32 lift_L = 0, u32 sigma_split = 0);
+// forward transform of the BV digits with the digit lift fused into the load (no digits kernel):
+// d2[nb][L][N] COEFFICIENT -> dig[nb][L(i)][L(j)][N] EVALUATION.  Returns false if the register-blocked
+// kernel does not cover this ring dimension as one slice (callers then use launch_digits + launch_ntt).
+// folded_layout: write the lane order of the folded configuration (two slices per limb), matching arrays
+// produced by launch_ntt(.., folded = true)
+bool launch_ntt_digits(const NttPlan &pl, const u64 *d2, u64 *dig, u32 nb, u32 L, bool sigma, bool folded_layout,
+                       hipStream_t st);
 void ntt_sigma_inverse_map(u32 logN, u32 s0, std::vector<u32> &map);  // s0 = ~0u: identity
 // sigma: keep the EVALUATION side in the register-blocked kernel's lane order (internal arrays only; ignored,
 // i.e. standard order, when that kernel does not apply -- ntt_sigma_inverse_map is then the identity)

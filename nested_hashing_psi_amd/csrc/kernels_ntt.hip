@@ -140,6 +140,13 @@ u32 ntt_fast_s0(u32 logN)
     return (logN - s0 >= 12 && logN - s0 <= 14) ? s0 : ~0u;
 }
 
+bool launch_ntt_digits(const NttPlan &pl, const u64 *d2, u64 *dig, u32 nb, u32 L, bool sigma, bool folded_layout, hipStream_t st)
+{
+    if (pl.force_generic || !pl.twp || !pl.twc || ntt_fast_s0(pl.logN) != 0) return false;
+    return launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, 0, dig, nb * L * L, 0, L, false, sigma, pl.num_cus, st, d2, L,
+                           (sigma && folded_layout) ? 1u : 0u);
+}
+
 void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, hipStream_t st, bool sigma,
                 bool folded)
 {

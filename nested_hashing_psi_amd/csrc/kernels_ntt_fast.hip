@@ -42,6 +42,12 @@ struct NttFastArgs {
     u32 s0;       // log2 slices per limb (stages below 2^s0 groups were done in global memory)
     u32 nitems;   // limbs << s0
     u32 sigma;    // EVALUATION side stored in lane order (see below) instead of standard bit-reversed order
+    // forward only, s0 = 0: BV digit lift fused into the load (replaces the digits kernel).  Item (bin, i, j)
+    // reads residue limb i of the COEFFICIENT polynomial lift_src[bin][i], lifts it (centred) into q_j and
+    // transforms it; lift_L = 0 disables.
+    const u64 *lift_src;
+    u32 lift_L;
+    u32 sigma_split;  // forward, lane order: store as if the limb were 2^sigma_split slices (the folded layout)
     u32 mod_base, mod_count;
 };
 
@@ -187,6 +193,15 @@ __device__ __forceinline__ constexpr int bfly_lo(int m, int d) { return ((m & ~(
         if (((cnt) % (every)) == (every) - 1) __builtin_amdgcn_sched_barrier(0); \
     } while (0)
 
+// centred lift of a residue mod q_i into q_j (same rule as digits_kernel / oracle keyswitch_acc)
+__device__ __forceinline__ u64 lift_digit(u64 v, u64 qi, u64 qi_mod_qj, const Mod &mj)
+{
+    // v < q_i; when q_i < 2 q_j (every chain of equal-width primes) one conditional subtraction reduces it
+    u64 r = (qi < 2 * mj.q) ? (v >= mj.q ? v - mj.q : v) : barrett128(0, v, mj);
+    if (v > qi / 2) r = submod(r, qi_mod_qj, mj.q);
+    return r;
+}
+
 template <int LOGN, bool INV, bool SIGMA>
 __global__ void __launch_bounds__((1 << LOGN) / 32)
 ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u64x2 *__restrict__ gtwc,
@@ -216,16 +231,31 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
     {
         const u64 *g = gdata + (size_t)item * n;
         const u32 st = (INV && SIGMA) ? 2 * T : NB;  // sigma order: pair k of thread tau at 2 (k T + tau)
+        if (!INV && a.lift_L) g = a.lift_src + (size_t)(item / a.lift_L) * n;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const u64x2 v = *reinterpret_cast<const u64x2 *>(g + 2 * tau + st * k);
             y[2 * k] = v.x;
             y[2 * k + 1] = v.y;
         }
+        if (!INV && a.lift_L) {
+            const u32 li = (item / a.lift_L) % a.lift_L, lj = item % a.lift_L;
+            const Mod mj = gdc->mod[lj];
+            const u64 qi = gdc->mod[li].q, qq = gdc->qi_modqj[li][lj];
+#pragma unroll
+            for (int k = 0; k < 32; k++) y[k] = lift_digit(y[k], qi, qq, mj);
+        }
     }
     int iter = 0;
     for (; item < a.nitems; item += gridDim.x, iter++) {
         STAMP(0);
+        if (!INV && a.lift_L && iter > 0) {  // digits prefetched during the previous slice: lift them now
+            const u32 li = (item / a.lift_L) % a.lift_L, lj = item % a.lift_L;
+            const Mod mj = gdc->mod[lj];
+            const u64 qi = gdc->mod[li].q, qq = gdc->qi_modqj[li][lj];
+#pragma unroll
+            for (int k = 0; k < 32; k++) y[k] = lift_digit(y[k], qi, qq, mj);
+        }
 #pragma unroll
         for (int k = 0; k < 32; k++) x[k] = y[k];
         const u32 next = item + gridDim.x;
@@ -281,7 +311,7 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
 #else
                     if (next < a.nitems) {
 #endif
-                        const u64 *gn = gdata + (size_t)next * n;
+                        const u64 *gn = a.lift_L ? a.lift_src + (size_t)(next / a.lift_L) * n : gdata + (size_t)next * n;
 #pragma unroll
                         for (int k = 0; k < 16; k++) {
                             const u64x2 v = *reinterpret_cast<const u64x2 *>(gn + 2 * tau + NB * k);
@@ -355,7 +385,9 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
                     r1 = r1 >= q2 ? r1 - q2 : r1;
                     v.x = r0 >= q ? r0 - q : r0;
                     v.y = r1 >= q ? r1 - q : r1;
-                    *reinterpret_cast<u64x2 *>(g + 2 * (k * T + tau)) = v;
+                    // lane order of a limb transformed as 2^sigma_split slices: slice tau / Ts, thread tau % Ts
+                    const u32 Ts = T >> a.sigma_split;
+                    *reinterpret_cast<u64x2 *>(g + (size_t)(tau / Ts) * (n >> a.sigma_split) + 2 * (k * Ts + tau % Ts)) = v;
                 }
                 continue;
             }
@@ -546,7 +578,8 @@ void ntt_sigma_inverse_map(u32 logN, u32 s0, std::vector<u32> &map)
 }
 
 bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
-                     u32 mod_count, bool inverse, bool sigma, u32 num_cus, hipStream_t st)
+                     u32 mod_count, bool inverse, bool sigma, u32 num_cus, hipStream_t st, const u64 *lift_src, u32 lift_L,
+                     u32 sigma_split)
 {
     const u32 logn = logN - s0;
     if (logn < 12 || logn > 14) return false;
@@ -560,6 +593,9 @@ bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N,
     a.s0 = s0;
     a.nitems = nlimbs << s0;
     a.sigma = sigma ? 1u : 0u;
+    a.lift_src = lift_src;
+    a.lift_L = (lift_src && !inverse && s0 == 0) ? lift_L : 0;
+    a.sigma_split = (!inverse && s0 == 0) ? sigma_split : 0;
     a.mod_base = mod_base;
     a.mod_count = mod_count;
     // resident workgroups per CU by LDS: 136 KiB -> 1, 68 KiB -> 2, 34 KiB -> 4

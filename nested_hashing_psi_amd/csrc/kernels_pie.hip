@@ -11,6 +11,9 @@ namespace piehip {
 
 static const u32 TPB = 256;
 
+static bool g_small_moduli = false;  // set per launch by the callers' context (all Q, P moduli < 2^60)
+void set_small_moduli(bool v) { g_small_moduli = v; }
+
 // ---------------------------------------------------------------------------------------------
 // Stage A (rows A3+A4): acc[beta][h][c][l][n] = sum_j idx[h][j][c][l][n] * db[h][beta][j][l][n] + minus[c][l][n]
 //
@@ -340,9 +343,6 @@ __global__ void __launch_bounds__(TPB) expand_kernel(const DevConsts *__restrict
     }
 }
 
-static bool g_small_moduli = false;  // set per launch by the callers' context (all Q, P moduli < 2^60)
-void set_small_moduli(bool v) { g_small_moduli = v; }
-
 static void launch_expand_common(bool scale, bool fold, const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t so, size_t si,
                                  u32 n_outer, u64 *out, u32 out_polys, u32 out_slot, hipStream_t st)
 {
@@ -499,7 +499,7 @@ __device__ __forceinline__ u64 digit_lift(const DevConsts *dc, u32 i, u32 j, u64
 {
     const Mod &mj = dc->mod[j];
     const u64 qi = dc->mod[i].q;
-    u64 r = barrett128(0, v, mj);
+    u64 r = (qi < 2 * mj.q) ? (v >= mj.q ? v - mj.q : v) : barrett128(0, v, mj);
     if (v > qi / 2) r = submod(r, dc->qi_modqj[i][j], mj.q);  // centred lift of the residue mod q_i
     return r;
 }
@@ -531,28 +531,75 @@ void launch_digits(const DevConsts *dc, u32 N, u32 L, const u64 *d2, size_t stri
         hipLaunchKernelGGL(digits_kernel<false>, grid, dim3(TPB), 0, st, dc, N, L, d2, stride2, dig);
 }
 
-__global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *dc, u32 N, u32 L, const u64 *__restrict__ d01,
+// One thread: two adjacent coefficients (16-byte lanes) of one (bin, limb j), both ciphertext components, so a
+// digit is loaded once for its two key products.  out_map (lane order -> standard) keeps pairs adjacent.
+template <bool MAD>
+__global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, const u64 *__restrict__ d01,
                                                         size_t stride01, const u64 *__restrict__ dig,
                                                         const u64 *__restrict__ key, const u64 *__restrict__ mask,
                                                         u64 *__restrict__ out, const u32 *__restrict__ out_map)
 {
-    const u32 n = blockIdx.x * TPB + threadIdx.x;
+    const u32 n = 2 * (blockIdx.x * TPB + threadIdx.x);
     if (n >= N) return;
-    const u32 c = blockIdx.y / L, j = blockIdx.y % L, bin = blockIdx.z;
+    const u32 j = blockIdx.y, bin = blockIdx.z;
     const Mod m = dc->mod[j];
     const size_t LN = (size_t)L * N;
-    U128 acc = {0, 0};
-    for (u32 i = 0; i < L; i++)
-        mac128(acc, dig[(((size_t)bin * L + i) * L + j) * N + n], key[(((size_t)i * 2 + c) * L + j) * N + n]);
-    u64 r = addmod(reduce128(acc, m), d01[(size_t)bin * stride01 + (size_t)c * LN + (size_t)j * N + n], m.q);
-    if (mask) r = mulmod(r, mask[(size_t)bin * LN + (size_t)j * N + n], m);
-    out[((size_t)bin * 2 + c) * LN + (size_t)j * N + (out_map ? out_map[n] : n)] = r;
+    U128 acc[2][2];
+    if (MAD) {
+        ColAcc a[2][2] = {{{0, 0, 0}, {0, 0, 0}}, {{0, 0, 0}, {0, 0, 0}}};
+        for (u32 i = 0; i < L; i++) {
+            const u64x2 d = *reinterpret_cast<const u64x2 *>(dig + (((size_t)bin * L + i) * L + j) * N + n);
+            const u64x2 k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)i * 2 + 0) * L + j) * N + n);
+            const u64x2 k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)i * 2 + 1) * L + j) * N + n);
+            const Split30 dx = split30(d.x), dy = split30(d.y);
+            colacc_mac(a[0][0], dx, split30(k0.x));
+            colacc_mac(a[0][1], dy, split30(k0.y));
+            colacc_mac(a[1][0], dx, split30(k1.x));
+            colacc_mac(a[1][1], dy, split30(k1.y));
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) acc[c][e] = colacc_value(a[c][e]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) acc[c][e] = U128{0, 0};
+        for (u32 i = 0; i < L; i++) {
+            const u64x2 d = *reinterpret_cast<const u64x2 *>(dig + (((size_t)bin * L + i) * L + j) * N + n);
+            const u64x2 k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)i * 2 + 0) * L + j) * N + n);
+            const u64x2 k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)i * 2 + 1) * L + j) * N + n);
+            mac128(acc[0][0], d.x, k0.x);
+            mac128(acc[0][1], d.y, k0.y);
+            mac128(acc[1][0], d.x, k1.x);
+            mac128(acc[1][1], d.y, k1.y);
+        }
+    }
+    u64x2 mk;
+    if (mask) mk = *reinterpret_cast<const u64x2 *>(mask + (size_t)bin * LN + (size_t)j * N + n);
+    const u32 po = out_map ? out_map[n] : n;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const u64x2 s = *reinterpret_cast<const u64x2 *>(d01 + (size_t)bin * stride01 + (size_t)c * LN + (size_t)j * N + n);
+        u64x2 r;
+        r.x = addmod(reduce128(acc[c][0], m), s.x, m.q);
+        r.y = addmod(reduce128(acc[c][1], m), s.y, m.q);
+        if (mask) {
+            r.x = mulmod(r.x, mk.x, m);
+            r.y = mulmod(r.y, mk.y, m);
+        }
+        *reinterpret_cast<u64x2 *>(out + ((size_t)bin * 2 + c) * LN + (size_t)j * N + po) = r;
+    }
 }
 void launch_relin_mac(const DevConsts *dc, u32 N, u32 L, const u64 *d01, size_t stride01, const u64 *dig, const u64 *key,
                       const u64 *mask, u64 *out, u32 nb, hipStream_t st, const u32 *out_map)
 {
-    dim3 grid((N + TPB - 1) / TPB, 2 * L, nb);
-    hipLaunchKernelGGL(relin_mac_kernel, grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map);
+    dim3 grid((N / 2 + TPB - 1) / TPB, L, nb);
+    if (g_small_moduli)
+        hipLaunchKernelGGL(relin_mac_kernel<true>, grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map);
+    else
+        hipLaunchKernelGGL(relin_mac_kernel<false>, grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -182,11 +182,19 @@ static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, c
     const u32 N = h->hp.N, L = h->hp.L;
     const size_t LN = h->LN();
     const double W = 8.0 * N;
-    {
-        ProfScope ps(h, PIEHIP_K_DIGITS, W * nb * (L + (double)L * L));
-        launch_digits(h->d_dc, N, L, w.d2c, LN, nb, w.dig, h->stream, fold && h->fold_on);
+    set_small_moduli(h->small_moduli);
+    bool fused = false;
+    if (h->sigma_on && h->d_twc && h->hp.logN <= 14) {  // digit lift inside the transform's load phase
+        ProfScope ps(h, PIEHIP_K_NTT_FWD, 16.0 * N * nb * L * L);
+        fused = launch_ntt_digits(h->plan, w.d2c, w.dig, nb, L, sigma && h->sigma_on, fold && h->fold_on, h->stream);
     }
-    ntt(h, w.dig, nb * L * L, 0, L, false, sigma, fold);
+    if (!fused) {
+        {
+            ProfScope ps(h, PIEHIP_K_DIGITS, W * nb * (L + (double)L * L));
+            launch_digits(h->d_dc, N, L, w.d2c, LN, nb, w.dig, h->stream, fold && h->fold_on);
+        }
+        ntt(h, w.dig, nb * L * L, 0, L, false, sigma, fold);
+    }
     {
         ProfScope ps(h, PIEHIP_K_RELIN, W * (nb * ((double)L * L + 2 * L + 2 * L + (mask ? L : 0)) + 2.0 * L * L));
         launch_relin_mac(h->d_dc, N, L, w.d01, 2 * LN, w.dig, key, mask, out, nb, h->stream,
