@@ -78,6 +78,28 @@ int piehip_load_db(piehip_handle h, uint32_t K, uint32_t b, uint32_t E, const ui
 int piehip_load_db_slots(piehip_handle h, uint32_t K, uint32_t b, uint32_t E, uint32_t B, const int64_t *slots,
                          const int64_t *mask_slots);
 
+/* The server's whole offline phase on the device (src/Server/FHE/BatchedFHEPSIServer.cpp:75-90):
+ * HierarchicalCuckooHashTable::insertAll (HierarchicalCuckooHashTable.cpp:55-72: k outer tabulation hashes into e
+ * positions, each a blocked Cuckoo table K x b x E with inner hash ids k..k+K-1) followed by the BatchedFHEHIPPIE
+ * constructor (BatchedFHEHIPPIE.cpp:23-82: bin-layer shuffle, gather into K*b*E packed plaintexts of B = k*e slots,
+ * b mask plaintexts).  items[n]: non-zero values < t (0 is the empty-cell sentinel, CuckooHashTable.cpp:89-90).
+ * hash_seed seeds TabulationHashing (TabulationHashing.cpp:16-36: std::mt19937 + uniform_int_distribution<uint64_t>);
+ * the reference seeds evictions, shuffle and masks from std::random_device -- here they are explicit.
+ * Errors: PIEHIP_EINVAL for bad sizes / items >= t, PIEHIP_EHASH when an insertion fails
+ * (the reference throws runtime_error("(Blocked) Cuckoo hashing error"), CuckooHashTable.cpp:113). */
+#define PIEHIP_EHASH (-5)
+int piehip_build_db(piehip_handle h, const uint64_t *items, size_t n, uint32_t k, uint32_t e, uint32_t K, uint32_t b,
+                    uint32_t E, uint64_t hash_seed, uint64_t evict_seed, uint64_t shuffle_seed, uint64_t mask_seed);
+/* Only the BatchedFHEHIPPIE constructor (BatchedFHEHIPPIE.cpp:23-82) on the device, for a hash table the caller
+ * built itself (the reference's HierarchicalCuckooHashTable): tbl[k][e][K][b][E] = hierarchicalCuckooTable[i][p]
+ * .cuckooTable[h][bin][j]; shuffles the bin layers, gathers, draws the masks and encodes. */
+int piehip_load_db_table(piehip_handle h, const uint64_t *tbl, uint32_t k, uint32_t e, uint32_t K, uint32_t b, uint32_t E,
+                         uint64_t shuffle_seed, uint64_t mask_seed);
+/* the table built by piehip_build_db, after the bin shuffle: tbl[k][e][K][b][E] (hierarchicalCuckooTable[i][p].cuckooTable) */
+int piehip_get_hash_table(piehip_handle h, uint64_t *tbl);
+/* TabulationHashing::hashWithIndicator for n inputs (host-side; no device needed) */
+int piehip_tabulation_hash(uint64_t hash_seed, uint32_t nfun, uint32_t hf, const uint64_t *x, size_t n, uint64_t *out);
+
 /* setIndex (BatchedFHEHIPPIE.hpp:40-43): idx[K][E][2][L][N];
  * setMinusCompareElement (BatchedFHEHIPPIE.hpp:45-48): minus[2][L][N]. */
 int piehip_set_index(piehip_handle h, const uint64_t *idx);

@@ -27,6 +27,10 @@ SYMBOLS = {
     "piehip_load_relin_key": (C.c_int, [C.c_void_p, u64p]),
     "piehip_load_db": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, u64p, u64p]),
     "piehip_load_db_slots": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, i64p, i64p]),
+    "piehip_build_db": (C.c_int, [C.c_void_p, u64p, C.c_size_t] + [C.c_uint32] * 5 + [C.c_uint64] * 4),
+    "piehip_load_db_table": (C.c_int, [C.c_void_p, u64p] + [C.c_uint32] * 5 + [C.c_uint64] * 2),
+    "piehip_get_hash_table": (C.c_int, [C.c_void_p, u64p]),
+    "piehip_tabulation_hash": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, u64p, C.c_size_t, u64p]),
     "piehip_set_index": (C.c_int, [C.c_void_p, u64p]),
     "piehip_set_minus": (C.c_int, [C.c_void_p, u64p]),
     "piehip_set_index_device": (C.c_int, [C.c_void_p, C.c_void_p]),

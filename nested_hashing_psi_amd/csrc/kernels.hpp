@@ -87,4 +87,13 @@ void launch_encode_scatter(const DevConsts *dc, u32 N, u32 M, const int64_t *slo
 // coefficients mod t [npt][N] -> centred lift into every q_i: out[npt][L][N]
 void launch_encode_lift(const DevConsts *dc, u32 N, u32 L, u32 M, const u64 *u, u64 *out, u32 npt, hipStream_t st);
 
+// ---- offline phase: nested hashing and database gather on the device (kernels_hash.hip) -----------------------
+size_t hash_sort_temp_bytes(u32 n, u32 e);
+hipError_t launch_hash_build(const u64 *d_tab, const u64 *d_items, u32 n, u32 k, u32 e, u32 K, u32 b, u32 E, u64 evict_seed,
+                             u64 shuffle_seed, u64 *d_tbl, u32 *d_keys, u32 *d_vals, u32 *d_start, void *d_temp, size_t temp_bytes,
+                             u32 *d_fail, hipStream_t st);
+void launch_shuffle_rows(u64 *d_tbl, u32 rows, u32 b, u32 E, u64 seed, hipStream_t st);
+void launch_gather_slots(const u64 *d_tbl, u32 B, u32 K, u32 b, u32 E, u64 t, int64_t *d_slots, u32 *d_fail, hipStream_t st);
+void launch_mask_slots(u64 t, u32 b, u32 B, u64 seed, int64_t *d_out, hipStream_t st);
+
 }  // namespace piehip

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <random>
 #include <string>
 #include <vector>
 
@@ -69,6 +70,8 @@ struct piehip_ctx {
     bool small_moduli = false;   // all Q and P moduli < 2^60
     bool sigma_on = false;       // the register-blocked NTT (and hence the lane order) applies to this context
     u64 *d_evk_sigma = nullptr, *d_masks_sigma = nullptr;  // lane-ordered copies of key and masks
+    u64 *d_hash_tbl = nullptr;   // [k][e][K][b][E] of the last piehip_build_db
+    u32 hk = 0, he = 0;
     NttPlan plan;
     // keys / database / inputs
     u64 *d_evk = nullptr;
@@ -141,6 +144,26 @@ static void dev_free(u64 **p)
     if (*p) (void)hipFree(*p);
     *p = nullptr;
 }
+
+namespace {
+struct Tmp {  // RAII device scratch for the synchronous test entry points
+    std::vector<u64 *> ptrs;
+    ~Tmp()
+    {
+        for (u64 *p : ptrs) (void)hipFree(p);
+    }
+    u64 *get(size_t words)
+    {
+        u64 *p = nullptr;
+        if (hipMalloc((void **)&p, (words ? words : 1) * sizeof(u64)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return p;
+    }
+};
+}  // namespace
+#define TMPGET(var, words)                                          \
+    u64 *var = tmp.get(words);                                      \
+    if (!var) return fail(PIEHIP_ENOMEM, "hipMalloc failed (scratch)")
 
 static int ws_alloc(piehip_ctx *h, MulWs &w, u32 nb)
 {
@@ -559,6 +582,131 @@ int piehip_load_db_slots(piehip_handle h, uint32_t K, uint32_t b, uint32_t E, ui
     return make_masks_sigma(h);
 }
 
+// TabulationHashing tables (TabulationHashing.cpp:16-36): [nfun][16][256], drawn in that order from
+// std::mt19937(seed) through std::uniform_int_distribution<uint64_t> -- the library types themselves, so the
+// stream is the reference's under libstdc++.
+static void tabulation_tables(uint64_t seed, uint32_t nfun, std::vector<u64> &tab)
+{
+    tab.resize((size_t)nfun * 16 * 256);
+    std::mt19937 gen(seed);
+    std::uniform_int_distribution<uint64_t> dis;
+    for (auto &v : tab) v = dis(gen);
+}
+
+int piehip_tabulation_hash(uint64_t hash_seed, uint32_t nfun, uint32_t hf, const uint64_t *x, size_t n, uint64_t *out)
+{
+    if (!x || !out || hf >= nfun) return fail(PIEHIP_EINVAL, "bad argument");
+    std::vector<u64> tab;
+    tabulation_tables(hash_seed, nfun, tab);
+    const u64 *t = tab.data() + (size_t)hf * 16 * 256;
+    for (size_t a = 0; a < n; a++) {
+        u64 v = x[a], res = 0;
+        for (int i = 0; i < 16; i++) {
+            res ^= t[i * 256 + (v & 0xff)];
+            v >>= 8;
+        }
+        out[a] = res;
+    }
+    return PIEHIP_OK;
+}
+
+int piehip_build_db(piehip_handle h, const uint64_t *items, size_t n, uint32_t k, uint32_t e, uint32_t K, uint32_t b, uint32_t E,
+                    uint64_t hash_seed, uint64_t evict_seed, uint64_t shuffle_seed, uint64_t mask_seed)
+{
+    NEED(h);
+    if (!items || !n || n > 0x7FFFFFFFu) return fail(PIEHIP_EINVAL, "empty or oversized server set");
+    if (k < 1 || e < 1) return fail(PIEHIP_EINVAL, "need at least one outer hash function and position");
+    const size_t B = (size_t)k * e;
+    if (B > h->hp.N) return fail(PIEHIP_EINVAL, "batch size k*e exceeds the ring dimension");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = alloc_run_buffers(h, K, b, E);
+    if (rc) return rc;
+    dev_free(&h->d_hash_tbl);
+    const size_t tbl_words = B * K * b * E;
+    if ((rc = dev_alloc(&h->d_hash_tbl, tbl_words))) return rc;
+    h->hk = k;
+    h->he = e;
+    std::vector<u64> tab;
+    tabulation_tables(hash_seed, k + K, tab);
+    Tmp tmp;
+    TMPGET(d_tab, tab.size());
+    TMPGET(d_items, n);
+    TMPGET(d_keys, n + 1);      // 2 n u32
+    TMPGET(d_vals, n + 1);      // 2 n u32
+    TMPGET(d_start, (e + 2) / 2 + 1);
+    TMPGET(d_failw, 1);
+    const size_t temp_bytes = hash_sort_temp_bytes((u32)n, e);
+    TMPGET(d_temp, temp_bytes / 8 + 1);
+    const size_t npt = (size_t)K * b * E;
+    TMPGET(d_slotsw, (npt > b ? npt : b) * B);
+    int64_t *d_slots = (int64_t *)d_slotsw;
+    u32 *d_fail = (u32 *)d_failw;
+    HIPCHK(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_items, items, n * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_hash_tbl, 0, tbl_words * sizeof(u64), h->stream));
+    HIPCHK(hipMemsetAsync(d_fail, 0, sizeof(u32), h->stream));
+    {
+        ProfScope ps(h, PIEHIP_K_OTHER, 8.0 * (double)n * k * 4);
+        HIPCHK(launch_hash_build(d_tab, d_items, (u32)n, k, e, K, b, E, evict_seed, shuffle_seed, h->d_hash_tbl, (u32 *)d_keys,
+                                 (u32 *)d_vals, (u32 *)d_start, d_temp, temp_bytes, d_fail, h->stream));
+        launch_gather_slots(h->d_hash_tbl, (u32)B, K, b, E, h->hp.t, d_slots, d_fail, h->stream);
+    }
+    u32 failed = 0;
+    HIPCHK(hipMemcpyAsync(&failed, d_fail, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (failed & 1u) return fail(PIEHIP_EHASH, "(Blocked) Cuckoo hashing error");
+    if (failed & 2u) return fail(PIEHIP_EINVAL, "server item does not fit the plaintext modulus");
+    if ((rc = encode_on_device(h, d_slots, (u32)npt, (u32)B, h->d_db))) return rc;
+    launch_mask_slots(h->hp.t, b, (u32)B, mask_seed, d_slots, h->stream);
+    if ((rc = encode_on_device(h, d_slots, b, (u32)B, h->d_masks))) return rc;
+    return make_masks_sigma(h);
+}
+
+int piehip_load_db_table(piehip_handle h, const uint64_t *tbl, uint32_t k, uint32_t e, uint32_t K, uint32_t b, uint32_t E,
+                         uint64_t shuffle_seed, uint64_t mask_seed)
+{
+    NEED(h);
+    if (!tbl || k < 1 || e < 1) return fail(PIEHIP_EINVAL, "bad hash table");
+    const size_t B = (size_t)k * e;
+    if (B > h->hp.N) return fail(PIEHIP_EINVAL, "batch size k*e exceeds the ring dimension");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = alloc_run_buffers(h, K, b, E);
+    if (rc) return rc;
+    dev_free(&h->d_hash_tbl);
+    const size_t tbl_words = B * K * b * E;
+    if ((rc = dev_alloc(&h->d_hash_tbl, tbl_words))) return rc;
+    h->hk = k;
+    h->he = e;
+    Tmp tmp;
+    const size_t npt = (size_t)K * b * E;
+    TMPGET(d_slotsw, (npt > b ? npt : b) * B);
+    TMPGET(d_failw, 1);
+    int64_t *d_slots = (int64_t *)d_slotsw;
+    u32 *d_fail = (u32 *)d_failw;
+    HIPCHK(hipMemcpyAsync(h->d_hash_tbl, tbl, tbl_words * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(d_fail, 0, sizeof(u32), h->stream));
+    launch_shuffle_rows(h->d_hash_tbl, (u32)(B * K), b, E, shuffle_seed, h->stream);
+    launch_gather_slots(h->d_hash_tbl, (u32)B, K, b, E, h->hp.t, d_slots, d_fail, h->stream);
+    u32 failed = 0;
+    HIPCHK(hipMemcpyAsync(&failed, d_fail, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (failed & 2u) return fail(PIEHIP_EINVAL, "server item does not fit the plaintext modulus");
+    if ((rc = encode_on_device(h, d_slots, (u32)npt, (u32)B, h->d_db))) return rc;
+    launch_mask_slots(h->hp.t, b, (u32)B, mask_seed, d_slots, h->stream);
+    if ((rc = encode_on_device(h, d_slots, b, (u32)B, h->d_masks))) return rc;
+    return make_masks_sigma(h);
+}
+
+int piehip_get_hash_table(piehip_handle h, uint64_t *tbl)
+{
+    NEED(h);
+    if (!tbl) return fail(PIEHIP_EINVAL, "null out");
+    if (!h->d_hash_tbl) return fail(PIEHIP_ESTATE, "no table: call piehip_build_db first");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpy(tbl, h->d_hash_tbl, sizeof(u64) * (size_t)h->hk * h->he * h->K * h->b * h->E, hipMemcpyDeviceToHost));
+    return PIEHIP_OK;
+}
+
 int piehip_set_index(piehip_handle h, const uint64_t *idx)
 {
     NEED(h);
@@ -677,25 +825,6 @@ int piehip_copy_results_device(piehip_handle h, void *d_dst)
 }
 
 // ---- kernel-level entry points (tests) -------------------------------------------------------------
-namespace {
-struct Tmp {  // RAII device scratch for the synchronous test entry points
-    std::vector<u64 *> ptrs;
-    ~Tmp()
-    {
-        for (u64 *p : ptrs) (void)hipFree(p);
-    }
-    u64 *get(size_t words)
-    {
-        u64 *p = nullptr;
-        if (hipMalloc((void **)&p, (words ? words : 1) * sizeof(u64)) != hipSuccess) return nullptr;
-        ptrs.push_back(p);
-        return p;
-    }
-};
-}  // namespace
-#define TMPGET(var, words)                                          \
-    u64 *var = tmp.get(words);                                      \
-    if (!var) return fail(PIEHIP_ENOMEM, "hipMalloc failed (scratch)")
 
 int piehip_ntt(piehip_handle h, uint64_t *limbs, uint32_t nlimbs, uint32_t mod_base, uint32_t mod_count, int inverse)
 {

@@ -99,38 +99,9 @@ public:
         const uint32_t k = hct.numberOfSimpleTables, e = hct.eachSimpleTableSize;
         const size_t B = (size_t)k * e;  // batch size, .cpp:41 (assumes simple multi table)
         if (B > cc.ringDimension()) throw std::invalid_argument("batch size exceeds the ring dimension");
-        const uint64_t t = cc.GetPlaintextModulus();
-
-        // shuffle the bin layers of every (sub-table, inner hash function) row, .cpp:28-35
-        std::vector<uint32_t> perm((size_t)k * e * K * b);
-        uint64_t s = shuffleSeed;
-        for (size_t row = 0; row < (size_t)k * e * K; row++) {
-            uint32_t *p = &perm[row * b];
-            for (uint32_t i = 0; i < b; i++) p[i] = i;
-            for (uint32_t i = b - 1; i > 0; i--) std::swap(p[i], p[next(s) % (i + 1)]);
-        }
-        // gather DB[h][bin][j][slot] = table[slot/e][slot%e].cuckooTable[h][perm(bin)][j], .cpp:48-66
-        std::vector<int64_t> slots((size_t)K * b * E * B);
-        for (uint32_t h = 0; h < K; h++)
-            for (uint32_t bin = 0; bin < b; bin++)
-                for (uint32_t j = 0; j < E; j++) {
-                    int64_t *dst = &slots[(((size_t)h * b + bin) * E + j) * B];
-                    for (size_t sl = 0; sl < B; sl++) {
-                        const uint32_t src_bin = perm[(sl * K + h) * b + bin];
-                        const uint64_t v = hct.table[((sl * K + h) * b + src_bin) * E + j];
-                        if (v >= t) throw std::invalid_argument("table item does not fit the plaintext modulus");
-                        dst[sl] = v > t / 2 ? (int64_t)v - (int64_t)t : (int64_t)v;
-                    }
-                }
-        // masks uniform in [1, t-1], .cpp:73-82
-        std::vector<int64_t> masks((size_t)b * B);
-        s = maskSeed;
-        for (auto &m : masks) {
-            const uint64_t v = next(s) % (t - 1) + 1;
-            m = v > t / 2 ? (int64_t)v - (int64_t)t : (int64_t)v;
-        }
-        // MakePackedPlaintext of all K*b*E + b vectors on the device, .cpp:68,81
-        PieContext::check(piehip_load_db_slots(cc.handle(), K, b, E, (uint32_t)B, slots.data(), masks.data()));
+        // bin-layer shuffle (.cpp:23-35), gather (.cpp:45-70), masks (.cpp:72-82) and MakePackedPlaintext (.cpp:68,81),
+        // all on the device
+        PieContext::check(piehip_load_db_table(cc.handle(), hct.table, k, e, K, b, E, shuffleSeed, maskSeed));
         resultList.resize(b);
     }
 

@@ -16,7 +16,7 @@ import numpy as np
 
 from ._lib import NKERNELS, f64p, i64p, lib, u32p, u64p
 
-EINVAL, ESTATE, EHIP, ENOMEM = -1, -2, -3, -4
+EINVAL, ESTATE, EHIP, ENOMEM, EHASH = -1, -2, -3, -4, -5
 
 
 def _check(rc):
@@ -27,12 +27,22 @@ def _check(rc):
         raise ValueError(msg)          # reference: std::invalid_argument
     if rc == ENOMEM:
         raise MemoryError(msg)
+    if rc == EHASH:
+        raise RuntimeError(msg)        # reference: runtime_error("(Blocked) Cuckoo hashing error")
     raise RuntimeError(msg)            # reference: std::runtime_error / OpenFHE exceptions
 
 
 def _u64(a):
     a = np.ascontiguousarray(a, dtype=np.uint64)
     return a, a.ctypes.data_as(u64p)
+
+
+def tabulation_hash(hash_seed, nfun, hf, x):
+    """TabulationHashing::hashWithIndicator (reference TabulationHashing.cpp:45-54), host side"""
+    xa, xp = _u64(np.atleast_1d(x))
+    out = np.zeros_like(xa)
+    _check(lib().piehip_tabulation_hash(hash_seed, nfun, hf, xp, len(xa), out.ctypes.data_as(u64p)))
+    return out
 
 
 def default_moduli(N, L):
@@ -174,14 +184,31 @@ class BatchedFHEHIPPIE:
     """
 
     def __init__(self, cryptoContext, vectorizedHCT=None, preCalcRandomMask=None, slots=None, mask_slots=None,
-                 serverStashSize=0, simpleMultiTables=True, cuckooMultiTables=True):
+                 serverStashSize=0, simpleMultiTables=True, cuckooMultiTables=True, serverSet=None, hashParams=None,
+                 hashTable=None, shuffle_seed=2, mask_seed=3):
         if serverStashSize != 0:
             raise ValueError("Error, batched FHE PIE does not support a stash (yet).")
         if not simpleMultiTables or not cuckooMultiTables:
             raise ValueError("Error, batched FHE PIE currently does not support combined tables.")
         self.cc = cryptoContext
         h = cryptoContext._h
-        if vectorizedHCT is not None:
+        if serverSet is not None:
+            # the whole offline phase on the device: nested hashing (HierarchicalCuckooHashTable::insertAll) +
+            # the reference constructor's shuffle / gather / encode.  hashParams: k, e, K, b, E, hash_seed,
+            # evict_seed, shuffle_seed, mask_seed
+            p = hashParams
+            items, ip = _u64(serverSet)
+            self.K, self.b, self.E = p["K"], p["b"], p["E"]
+            _check(lib().piehip_build_db(h, ip, len(items), p["k"], p["e"], p["K"], p["b"], p["E"], p.get("hash_seed", 987654321),
+                                         p.get("evict_seed", 1), p.get("shuffle_seed", 2), p.get("mask_seed", 3)))
+            self._tbl_shape = (p["k"], p["e"], p["K"], p["b"], p["E"])
+        elif hashTable is not None:
+            # the reference constructor proper: hct.hierarchicalCuckooTable [k][e][K][b][E] -> shuffle, gather, encode
+            tbl, tp = _u64(hashTable)
+            k, e, self.K, self.b, self.E = tbl.shape
+            _check(lib().piehip_load_db_table(h, tp, k, e, self.K, self.b, self.E, shuffle_seed, mask_seed))
+            self._tbl_shape = tbl.shape
+        elif vectorizedHCT is not None:
             db, dbp = _u64(vectorizedHCT)
             mk, mkp = _u64(preCalcRandomMask)
             self.K, self.b, self.E = db.shape[0], db.shape[1], db.shape[2]
@@ -198,6 +225,12 @@ class BatchedFHEHIPPIE:
                 raise ValueError("slot value out of range for the plaintext modulus")
             _check(lib().piehip_load_db_slots(h, self.K, self.b, self.E, B, s.ctypes.data_as(i64p), m.ctypes.data_as(i64p)))
         self._keep = []
+
+    def hashTable(self):
+        """hierarchicalCuckooTable after the bin shuffle, [k][e][K][b][E] (only after a serverSet build)"""
+        out = np.zeros(self._tbl_shape, dtype=np.uint64)
+        _check(lib().piehip_get_hash_table(self.cc._h, out.ctypes.data_as(u64p)))
+        return out
 
     def setIndex(self, indexMatrix):
         a, ap = _u64(indexMatrix)

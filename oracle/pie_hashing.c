@@ -141,13 +141,16 @@ int ph_hct_build(const ph_tab *h, const uint64_t *items, size_t n, uint32_t k, u
     return rc;
 }
 
+/* one independent generator per (sub-table, inner hash function) row -- rows can then be shuffled in parallel
+ * (the GPU offline phase does); the reference draws from one std::random_device-seeded stream, so any
+ * permutation is equally faithful (BatchedFHEHIPPIE.cpp:25-35) */
 void ph_hct_shuffle_bins(uint64_t *tbl, uint32_t k, uint32_t e, uint32_t K, uint32_t b, uint32_t E, uint64_t seed)
 {
-    po_rng r;
-    po_rng_seed(&r, seed);
     uint64_t *tmp = (uint64_t *)malloc(sizeof(uint64_t) * E);
     for (size_t s = 0; s < (size_t)k * e; s++)
         for (uint32_t hf = 0; hf < K; hf++) {
+            po_rng r;
+            po_rng_seed(&r, seed * 0x100000001B3ULL + (s * K + hf));
             uint64_t *row = tbl + (s * K + hf) * (size_t)b * E; /* b layers of E */
             for (uint32_t i = b - 1; i > 0; i--) {
                 uint32_t j = (uint32_t)po_rng_below(&r, i + 1);
@@ -172,11 +175,23 @@ void ph_pack_db(const uint64_t *tbl, uint32_t k, uint32_t e, uint32_t K, uint32_
             }
 }
 
+/* counter-based: mask(bin, slot) = 1 + floor(mix(seed, bin, slot) * (t-1) / 2^64), mix = splitmix64 finaliser.
+ * Uniform over [1, t-1] up to a 2^-31 bias (BatchedFHEHIPPIE.cpp:79 uses randGen(mt) % (t-1) + 1, biased too). */
+static uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
 void ph_masks(uint64_t t, uint32_t b, uint32_t B, uint64_t seed, int64_t *masks)
 {
-    po_rng r;
-    po_rng_seed(&r, seed);
-    for (size_t i = 0; i < (size_t)b * B; i++) masks[i] = (int64_t)(po_rng_below(&r, t - 1) + 1);
+    for (uint32_t bin = 0; bin < b; bin++)
+        for (uint32_t s = 0; s < B; s++) {
+            uint64_t x = mix64(mix64(seed) ^ (((uint64_t)bin << 32) | s));
+            uint64_t v = (uint64_t)(((unsigned __int128)x * (t - 1)) >> 64) + 1;
+            masks[(size_t)bin * B + s] = (int64_t)v;
+        }
 }
 
 int ph_client_build(const ph_tab *h, const uint64_t *items, size_t n, uint32_t k, uint32_t e, uint64_t evict_seed,

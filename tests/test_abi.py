@@ -72,3 +72,16 @@ def test_cpp_facade_compiles_and_links(built, tmp_path):
     rc = subprocess.call([exe])
     import torch
     assert rc == (0 if torch.cuda.is_available() else 77)
+
+
+def test_tabulation_hash_matches_oracle(built, ob):
+    """product-side TabulationHashing (std::mt19937 + uniform_int_distribution, as the reference) == oracle restatement"""
+    from nested_hashing_psi_amd import pie
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 1 << 63, 500, dtype=np.uint64)
+    x[0], x[1] = 0, np.uint64((1 << 64) - 1)
+    for seed in (987654321, 12223222, 342797434736):
+        tab = ob.Tabulation(seed, 4)
+        for hf in range(4):
+            got = pie.tabulation_hash(seed, 4, hf, x)
+            assert [int(v) for v in got] == [tab.hash(int(v), hf) for v in x]

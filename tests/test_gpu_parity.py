@@ -239,3 +239,66 @@ def test_cpp_facade_runs_reference_call_order(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(root, "tests", "facade_check.cpp"),
                            "-L" + libdir, "-lpiehip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     assert subprocess.call([exe]) == 0
+
+
+@pytest.mark.parametrize("N,L,t,nS,k,e,K,E,b", [
+    (4096, 2, T16, 300, 2, 12, 2, 6, 6),
+    (2048, 3, T32, 5000, 3, 100, 2, 10, 6),
+    (16384, 4, T32, 1 << 17, 2, 1000, 2, 14, 8),
+    (1024, 2, T16, 40, 2, 3, 3, 5, 2),
+])
+def test_offline_phase_on_device(ob, pie, N, L, t, nS, k, e, K, E, b):
+    """piehip_build_db == oracle ph_hct_build + ph_hct_shuffle_bins + ph_pack_db + ph_masks + encode, bit for bit:
+    the hash table itself and the resulting run() output"""
+    from tests.test_oracle_pie import distinct_items
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(nS)
+    server = distinct_items(rng, t, nS)
+    seeds = dict(hash_seed=987654321, evict_seed=11, shuffle_seed=22, mask_seed=33)
+    op = pie.BatchedFHEHIPPIE(cc, serverSet=server, hashParams=dict(k=k, e=e, K=K, b=b, E=E, **seeds))
+    tab = ob.Tabulation(seeds["hash_seed"], k + K)
+    tbl = ob.hct_build(tab, server, k, e, K, b, E, evict_seed=seeds["evict_seed"])
+    ob.hct_shuffle_bins(tbl, seeds["shuffle_seed"])
+    assert (op.hashTable() == tbl).all()
+    # every server item sits in each of the k outer tables exactly once
+    assert int((tbl != 0).sum()) == k * nS
+    slots = ob.pack_db(tbl)
+    mask_slots = ob.masks(t, b, k * e, seeds["mask_seed"])
+    sk = o.keygen(1)
+    evk = o.relin_keygen(sk, 2)
+    cc.load_relin_key(evk)
+    B = k * e
+    rng2 = np.random.default_rng(5)
+    idx = np.stack([o.encrypt_slots(sk, rng2.integers(0, 2, B), 10 + i) for i in range(K * E)]).reshape(K, E, 2, L, N)
+    minus = o.encrypt_slots(sk, -rng2.integers(1, 1000, B), 9)
+    op.setMinusCompareElement(minus)
+    op.setIndex(idx)
+    op.run()
+    got = op.getResultList()
+    op2 = pie.BatchedFHEHIPPIE(cc, slots=slots, mask_slots=mask_slots)
+    op2.setMinusCompareElement(minus)
+    op2.setIndex(idx)
+    op2.run()
+    assert (got == op2.getResultList()).all()
+    # constructor-only path: a table built elsewhere (here: by the oracle, unshuffled) handed to the device
+    tbl0 = ob.hct_build(tab, server, k, e, K, b, E, evict_seed=seeds["evict_seed"])
+    op3 = pie.BatchedFHEHIPPIE(cc, hashTable=tbl0, shuffle_seed=seeds["shuffle_seed"], mask_seed=seeds["mask_seed"])
+    assert (op3.hashTable() == tbl).all()
+    op3.setMinusCompareElement(minus)
+    op3.setIndex(idx)
+    op3.run()
+    assert (got == op3.getResultList()).all()
+    cc.close()
+
+
+def test_offline_phase_errors(ob, pie):
+    cc = pie.PieContext(1024, 2, T16)
+    items = np.arange(1, 400, dtype=np.uint64)
+    with pytest.raises(RuntimeError, match="Cuckoo"):   # 399 items cannot fit 2*2 tables of 2*1*3 cells
+        pie.BatchedFHEHIPPIE(cc, serverSet=items, hashParams=dict(k=2, e=2, K=2, b=1, E=3))
+    with pytest.raises(ValueError, match="plaintext modulus"):
+        pie.BatchedFHEHIPPIE(cc, serverSet=np.array([T16 + 5], dtype=np.uint64), hashParams=dict(k=2, e=2, K=2, b=2, E=3))
+    with pytest.raises(ValueError, match="ring dimension"):
+        pie.BatchedFHEHIPPIE(cc, serverSet=items, hashParams=dict(k=2, e=600, K=2, b=2, E=3))
+    cc.close()
