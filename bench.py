@@ -73,9 +73,90 @@ def cpu_baseline(cfg, seconds_target=12.0):
         o.pie_run(idx, minus, db1, m1, evk)
         done += 1
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "ciphertexts/s", "cores": 1, "kind": "port",
-            "sample": "%d bin layers of the %s workload (K=%d, E=%d; 1 ct x ct + %d ct x pt MACs each), %.1f s; "
-                      "CPU restatement in C (oracle/), OpenFHE not available" % (done, cfg["name"], K, E, K * E, dt)}
+    out = {"value": done / dt, "unit": "ciphertexts/s", "cores": 1, "kind": "port",
+           "sample": "%d bin layers of the %s workload (K=%d, E=%d; 1 ct x ct + %d ct x pt MACs each), %.1f s; "
+                     "CPU restatement in C (oracle/), OpenFHE not available" % (done, cfg["name"], K, E, K * E, dt)}
+    # the same end-to-end PSI as e2e_psi(), every phase on one host core (encode of the K*b*E+b plaintexts
+    # extrapolated from a sample of 16 to keep this leg bounded)
+    k, e, nS, nC = cfg["k"], cfg["e"], cfg["S"], cfg["C"]
+    items = np.unique(rng.integers(1, t, nS + nC + 8192, dtype=np.uint64))
+    rng.shuffle(items)
+    server, ninter = items[:nS].copy(), nC // 2 + 1
+    clientset = np.concatenate([server[:ninter], items[nS:nS + nC - ninter]])
+    t0 = time.perf_counter()
+    sk = o.keygen(11)
+    evk2 = o.relin_keygen(sk, 12)
+    t1 = time.perf_counter()
+    tab = ob.Tabulation(987654321, k + K)
+    tbl = ob.hct_build(tab, server, k, e, K, b, E, evict_seed=1)
+    ob.hct_shuffle_bins(tbl, 2)
+    slots = ob.pack_db(tbl)
+    ta = time.perf_counter()
+    for i in range(16):
+        o.encode_eval(slots[0, 0, i % E])
+    enc_each = (time.perf_counter() - ta) / 16
+    t2 = time.perf_counter() + enc_each * (K * b * E + b - 16)
+    ctab = ob.client_build(tab, clientset, k, e)
+    index, minus_v = ob.client_vectors(tab, ctab, K, E)
+    tb_ = time.perf_counter()
+    for h in range(K):
+        for j in range(E):
+            o.encrypt_slots(sk, index[h, j], 100 + h * E + j)
+    o.encrypt_slots(sk, minus_v, 99)
+    client_off = time.perf_counter() - tb_
+    run_s = b * per_bin
+    ct = rl((2,))
+    tc = time.perf_counter()
+    o.decrypt_slots(sk, ct, k * e)
+    dec_s = (time.perf_counter() - tc) * b
+    out["e2e_psi_cpu_s"] = {"setup_s": t1 - t0, "server_offline_s": (t2 - t1), "client_offline_s": client_off,
+                            "server_online_s": run_s, "client_online_s": dec_s,
+                            "total_s": (t1 - t0) + (t2 - t1) + client_off + run_s + dec_s}
+    return out
+
+
+def e2e_psi(cfg, pie, cc, device_sync):
+    """End-to-end PSI wall-clock (the second half of BASELINE.json's metric), in process, no TCP: what the
+    reference client times as Setup + Offline + Online (src/Client/PSIClient.hpp:87-116).  Server offline phase
+    (nested hashing + packing) and the client's BFV operations run on the device, ciphertexts cross PCIe as
+    host arrays exactly once each way.  Sets: distinct uniform non-zero items < t, |I| = |C|/2 + 1
+    (Parameters1.txt column 3), hash seed 987654321 (CLI.cpp:67)."""
+    from nested_hashing_psi_amd.client import BatchedFHEPSIClient
+    t, k, e, K, E, b = cfg["t"], cfg["k"], cfg["e"], cfg["K"], cfg["E"], cfg["b"]
+    nS, nC = cfg["S"], cfg["C"]
+    rng = np.random.default_rng(123456789)
+    items = np.unique(rng.integers(1, t, nS + nC + 8192, dtype=np.uint64))
+    rng.shuffle(items)
+    server = items[:nS].copy()
+    ninter = nC // 2 + 1
+    clientset = np.concatenate([server[:ninter], items[nS:nS + nC - ninter]])
+    rng.shuffle(clientset)
+    out = {}
+    t0 = time.perf_counter()
+    cl = BatchedFHEPSIClient(cc, k, e, K, E, b)
+    evk = cl.runSetUpPhase()
+    cc.load_relin_key(evk)
+    device_sync()
+    t1 = time.perf_counter()
+    srv = pie.BatchedFHEHIPPIE(cc, serverSet=server, hashParams=dict(k=k, e=e, K=K, b=b, E=E))
+    device_sync()
+    t2 = time.perf_counter()
+    minus_ct, idx_ct = cl.runOfflinePhase(clientset)
+    device_sync()
+    t3 = time.perf_counter()
+    srv.setMinusCompareElement(minus_ct)
+    srv.setIndex(idx_ct)
+    srv.run()
+    res = srv.getResultList()
+    t4 = time.perf_counter()
+    found = cl.extractIntersection(res)
+    t5 = time.perf_counter()
+    ok = sorted(int(v) for v in found) == sorted(int(v) for v in server[:ninter])
+    out.update(setup_s=t1 - t0, server_offline_s=t2 - t1, client_offline_s=t3 - t2, server_online_s=t4 - t3,
+               client_online_s=t5 - t4, total_s=t5 - t0, intersection_size=int(len(found)), intersection_correct=bool(ok),
+               note="in-process, no TCP; includes PCIe transfers of keys, %d input and %d result ciphertexts; server offline = "
+                    "device hashing + packing of |S|=%d items" % (K * E + 1, b, nS))
+    return out
 
 
 def pmc_traffic(config):
@@ -100,6 +181,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end PSI wall-clock leg")
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: run the RCCL gather path even with one rank (launch under torch.distributed.run)")
     args = ap.parse_args()
@@ -247,9 +329,13 @@ def main():
             "mac_per_s": b_total * K * E / (ms_per_step * 1e-3),
             "roofline": roofline, "kernels": kernels,
         }
+        if not args.no_e2e and world == 1:
+            line["e2e_psi"] = e2e_psi(cfg, pie, cc, lambda: torch.cuda.synchronize(device))
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg)
             line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]
+            if "e2e_psi" in line:
+                line["e2e_speedup_vs_cpu_1core"] = line["cpu_baseline"]["e2e_psi_cpu_s"]["total_s"] / line["e2e_psi"]["total_s"]
         print(json.dumps(line))
     if dist:
         dist.barrier()

@@ -140,6 +140,23 @@ int piehip_encode(piehip_handle h, const int64_t *slots, uint32_t npt, uint32_t 
  * which = 2: scale by t/P from QP into Q      in[npoly][2L+1][N] -> out[npoly][L][N] */
 int piehip_base_convert(piehip_handle h, int which, const uint64_t *in, uint32_t npoly, uint64_t *out);
 
+/* ---- client-side harness -----------------------------------------------------------------------------
+ * Not part of the server hot path: the client role of src/Client/FHE/BatchedFHEPSIClient.cpp, needed to
+ * produce the hot path's inputs, to read its outputs and to measure the end-to-end PSI wall-clock
+ * (SURVEY.md 8f-1).  Deterministic samplers (xoshiro256** streams seeded per call) run on the host, the
+ * polynomial arithmetic on the device.  BFV conventions: secret key uniform ternary; noise centred
+ * binomial (sigma 3.16); fresh ciphertext (c0, c1) = (-a s + e + round(Q m / t), a); all in EVALUATION format. */
+/* KeyGen (BatchedFHEPSIClient.cpp:88): sk[L][N] */
+int piehip_client_keygen(piehip_handle h, uint64_t seed, uint64_t *sk);
+/* EvalMultKeyGen (BatchedFHEPSIClient.cpp:91): BV key, evk[L][2][L][N] */
+int piehip_client_relin_keygen(piehip_handle h, const uint64_t *sk, uint64_t seed, uint64_t *evk);
+/* MakePackedPlaintext + Encrypt(secretKey, .) (BatchedFHEPSIClient.cpp:155-156,161-168) of nct slot vectors
+ * slots[nct][B]; seeds[nct] one sampler seed per ciphertext; out[nct][2][L][N] */
+int piehip_client_encrypt(piehip_handle h, const uint64_t *sk, const int64_t *slots, uint32_t nct, uint32_t B,
+                          const uint64_t *seeds, uint64_t *out);
+/* Decrypt + GetPackedValue (BatchedFHEPSIClient.cpp:249-265): ct[nct][2][L][N] -> slots[nct][B] (centred) */
+int piehip_client_decrypt(piehip_handle h, const uint64_t *sk, const uint64_t *ct, uint32_t nct, uint32_t B, int64_t *slots);
+
 /* ---- measurement ------------------------------------------------------------------------------
  * With profiling on, run() brackets every kernel launch with HIP events on the handle's stream.
  * piehip_profile_read returns, per kernel class, the launch count, total milliseconds, and the

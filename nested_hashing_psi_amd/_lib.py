@@ -48,6 +48,10 @@ SYMBOLS = {
     "piehip_encode": (C.c_int, [C.c_void_p, i64p, C.c_uint32, C.c_uint32, u64p]),
     "piehip_base_convert": (C.c_int, [C.c_void_p, C.c_int, u64p, C.c_uint32, u64p]),
     "piehip_bench_ntt": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, f64p]),
+    "piehip_client_keygen": (C.c_int, [C.c_void_p, C.c_uint64, u64p]),
+    "piehip_client_relin_keygen": (C.c_int, [C.c_void_p, u64p, C.c_uint64, u64p]),
+    "piehip_client_encrypt": (C.c_int, [C.c_void_p, u64p, i64p, C.c_uint32, C.c_uint32, u64p, u64p]),
+    "piehip_client_decrypt": (C.c_int, [C.c_void_p, u64p, u64p, C.c_uint32, C.c_uint32, i64p]),
     "piehip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "piehip_profile_read": (C.c_int, [C.c_void_p, u32p, f64p, f64p]),
 }

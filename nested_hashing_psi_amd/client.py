@@ -1,0 +1,108 @@
+"""Client-side harness: the role of the reference's BatchedFHEPSIClient
+(src/Client/FHE/BatchedFHEPSIClient.cpp), enough to drive the server hot path with real inputs, read
+its outputs and measure the end-to-end PSI wall-clock.  Harness, not the product:
+the product is the server path.  Hashing of the (small) client set runs on the host; BFV key
+generation, encryption and decryption run on the device through the C ABI (piehip_client_*).
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import i64p, lib, u64p
+from .pie import _check, _u64, tabulation_hash
+
+
+class BatchedFHEPSIClient:
+    """Mirror of BatchedFHEPSIClient (BatchedFHEPSIClient.cpp:14-193): runSetUpPhase, runOfflinePhase,
+    the online-phase result extraction.  No TCP: the caller moves the arrays."""
+
+    def __init__(self, cryptoContext, numberOfSimpleHashFunctions, eachSimpleTableSize, numberOfCuckooHashFunctions,
+                 eachCuckooTableSize, maxItemsPerPosition, hashSeed=987654321):
+        self.cc = cryptoContext
+        self.k, self.e = numberOfSimpleHashFunctions, eachSimpleTableSize
+        self.K, self.E, self.b = numberOfCuckooHashFunctions, eachCuckooTableSize, maxItemsPerPosition
+        self.hashSeed = hashSeed
+        self.B = self.k * self.e
+
+    # -- setup (BatchedFHEPSIClient.cpp:88-91): KeyGen + EvalMultKeyGen
+    def runSetUpPhase(self, keySeed=11, evalKeySeed=12):
+        cc = self.cc
+        self.sk = np.zeros((cc.L, cc.N), dtype=np.uint64)
+        _check(lib().piehip_client_keygen(cc._h, keySeed, self.sk.ctypes.data_as(u64p)))
+        self.evalMultKey = np.zeros((cc.L, 2, cc.L, cc.N), dtype=np.uint64)
+        _check(lib().piehip_client_relin_keygen(cc._h, self.sk.ctypes.data_as(u64p), evalKeySeed,
+                                                self.evalMultKey.ctypes.data_as(u64p)))
+        return self.evalMultKey
+
+    # -- client Cuckoo table: CuckooHashTable(hash, e, k, startingHashId 0, stash 0, multi, 1 layer)
+    #    (BatchedFHEPSIClient.cpp:97-99, insertAll at :109; insert at CuckooHashTable.cpp:72-114)
+    def _hash_client_set(self, items):
+        items = np.ascontiguousarray(items, dtype=np.uint64)
+        k, e = self.k, self.e
+        pos = np.stack([tabulation_hash(self.hashSeed, k + self.K, hf, items) % np.uint64(e) for hf in range(k)])
+        where = {int(x): i for i, x in enumerate(items)}
+        table = np.zeros((k, e), dtype=np.uint64)
+        for a, x in enumerate(items):
+            x = int(x)
+            if any(int(table[hf, pos[hf, where[x]]]) == x for hf in range(k)):  # lookUp: duplicate
+                continue
+            placed = False
+            for _ in range(1000):                                  # numberOfRetries
+                for hf in range(k):
+                    p = int(pos[hf, where[x]]) if x in where else int(tabulation_hash(self.hashSeed, k + self.K, hf, [x])[0] % e)
+                    if table[hf, p] == 0:
+                        table[hf, p] = x
+                        placed = True
+                        break
+                    x, table[hf, p] = int(table[hf, p]), x         # one layer: evict the occupant
+                if placed:
+                    break
+            if not placed:
+                raise RuntimeError("(Blocked) Cuckoo hashing error")
+        return table
+
+    # -- offline (BatchedFHEPSIClient.cpp:107-169): index matrix + minus vector, secret-key encrypted
+    def runOfflinePhase(self, clientSet, encSeedBase=100):
+        self.clientTable = self._hash_client_set(clientSet)
+        k, e, K, E, B = self.k, self.e, self.K, self.E, self.B
+        flat = self.clientTable.reshape(-1)
+        index = np.zeros((K, E, B), dtype=np.int64)
+        minus = np.ones(B, dtype=np.int64)                         # dummy slot: +1, all-zero index column (:128-131)
+        occ = np.nonzero(flat)[0]
+        if len(occ):
+            minus[occ] = -flat[occ].astype(np.int64)
+            for hf in range(K):
+                hi = tabulation_hash(self.hashSeed, k + K, k + hf, flat[occ]) % np.uint64(E)
+                index[hf, hi.astype(np.int64), occ] = 1
+        self.plainIndex, self.plainMinus = index, minus
+        vecs = np.concatenate([minus.reshape(1, B), index.reshape(K * E, B)])
+        seeds = np.array([encSeedBase - 1] + [encSeedBase + i for i in range(K * E)], dtype=np.uint64)
+        cts = self._encrypt(vecs, seeds)
+        self.encryptedMinusElements = cts[0]
+        self.batchedEncryptedIndexMatrix = cts[1:].reshape(K, E, 2, self.cc.L, self.cc.N)
+        return self.encryptedMinusElements, self.batchedEncryptedIndexMatrix
+
+    def _encrypt(self, vecs, seeds):
+        cc = self.cc
+        v = np.ascontiguousarray(vecs, dtype=np.int64)
+        out = np.zeros((v.shape[0], 2, cc.L, cc.N), dtype=np.uint64)
+        s = np.ascontiguousarray(seeds, dtype=np.uint64)
+        _check(lib().piehip_client_encrypt(cc._h, self.sk.ctypes.data_as(u64p), v.ctypes.data_as(i64p), v.shape[0], v.shape[1],
+                                           s.ctypes.data_as(u64p), out.ctypes.data_as(u64p)))
+        return out
+
+    def decrypt(self, cts, nslots=None):
+        cc = self.cc
+        a, ap = _u64(cts)
+        n = a.shape[0]
+        nslots = nslots or self.B
+        out = np.zeros((n, nslots), dtype=np.int64)
+        _check(lib().piehip_client_decrypt(cc._h, self.sk.ctypes.data_as(u64p), ap, n, nslots, out.ctypes.data_as(i64p)))
+        return out
+
+    # -- online (BatchedFHEPSIClient.cpp:176-192): zero slot in any of the b results <=> item in the intersection
+    def extractIntersection(self, resultList):
+        self.batchedDecryptedResult = self.decrypt(resultList)
+        flat = self.clientTable.reshape(-1)
+        hit = (self.batchedDecryptedResult == 0).any(axis=0)
+        return flat[hit].copy()

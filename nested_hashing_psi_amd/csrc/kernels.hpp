@@ -96,4 +96,14 @@ void launch_shuffle_rows(u64 *d_tbl, u32 rows, u32 b, u32 E, u64 seed, hipStream
 void launch_gather_slots(const u64 *d_tbl, u32 B, u32 K, u32 b, u32 E, u64 t, int64_t *d_slots, u32 *d_fail, hipStream_t st);
 void launch_mask_slots(u64 t, u32 b, u32 B, u64 seed, int64_t *d_out, hipStream_t st);
 
+// ---- client harness (kernels_client.hip) ----------------------------------------------------------------------------
+void launch_enc_message(const DevConsts *dc, u32 N, u32 L, u32 M, const u64 *coeff_t, const int32_t *e, u64 *em, u32 nct, hipStream_t st);
+void launch_enc_finish(const DevConsts *dc, u32 N, u32 L, const u64 *em, const u64 *sk, u64 *out, u32 nct, hipStream_t st);
+void launch_ks_finish(const DevConsts *dc, u32 N, u32 L, const u64 *e, const u64 *sk, const u64 *s_from, u64 *ks, hipStream_t st);
+void launch_square(const DevConsts *dc, u32 N, u32 L, const u64 *s, u64 *s2, hipStream_t st);
+void launch_dec_dot(const DevConsts *dc, u32 N, u32 L, const u64 *ct, const u64 *sk, u64 *xs, u32 nct, hipStream_t st);
+void launch_dec_round(const DevConsts *dc, u32 N, u32 L, u32 M, const u64 *xs, u64 *coeff_t, u32 nct, hipStream_t st);
+void launch_decode_gather(const DevConsts *dc, u32 N, u32 M, const u64 *u, const u32 *slot_pos, u32 B, int64_t *slots, u32 nct,
+                          hipStream_t st);
+
 }  // namespace piehip

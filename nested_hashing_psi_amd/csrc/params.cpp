@@ -209,6 +209,8 @@ std::string HostParams::init(u32 N_, u32 L_, u64 t_, const u64 *q, const u64 *p)
             dc.PI_modp[i][j] = v ? pj - v : 0;
         }
         for (u32 j = 0; j < L; j++) dc.qi_modqj[i][j] = qi % Q[j];
+        dc.t_inv_modq[i] = invmod(t % qi, qi);
+        dc.t_modq_sh[i] = shoup(t % qi, qi);
     }
     for (u32 j = 0; j < Lp; j++) {
         const u64 pj = P[j];
@@ -225,6 +227,7 @@ std::string HostParams::init(u32 N_, u32 L_, u64 t_, const u64 *q, const u64 *p)
             dc.tQF_modq[j][i] = v ? qi - v : 0;
         }
     }
+    dc.Q_modt = prod_mod(Q, L, -1, t);
     for (u32 a = 0; a < M; a++) {
         dc.qp_hat_inv[a] = invmod(prod_mod(moduli.data(), M, (int)a, moduli[a]), moduli[a]);
         dc.qp_hat_inv_sh[a] = shoup(dc.qp_hat_inv[a], moduli[a]);
