@@ -140,6 +140,32 @@ int piehip_encode(piehip_handle h, const int64_t *slots, uint32_t npt, uint32_t 
  * which = 2: scale by t/P from QP into Q      in[npoly][2L+1][N] -> out[npoly][L][N] */
 int piehip_base_convert(piehip_handle h, int which, const uint64_t *in, uint32_t npoly, uint64_t *out);
 
+/* ---- FHEHIPPIE: the rotation-based sibling operator ---------------------------------
+ * Reference: src/Common/Crypto/PrivateIndexedEqualityCheck/FHEHIPPIE.{hpp,cpp}; one operator per client slot
+ * (FHEHIPPIECollection, PIECollection.hpp); `npie` operators are evaluated as one batch here.
+ * An operator holds a flat blocked Cuckoo table T[K][b][E] with b == E (FHEHIPPIE.cpp:13-16), packs row (hf, bin)
+ * as the E table cells followed by a 1 (FHEHIPPIE.cpp:41-51), and evaluates per hash function
+ *   EvalMult(EvalMerge_bin(EvalInnerProduct(index[hf], row[hf][bin], b)), mask[hf])        (FHEHIPPIE.cpp:61-77)
+ * where EvalInnerProduct = EvalMult(ct, pt) + ceil(log2 b) rotate-by-2^r-and-add steps and EvalMerge masks
+ * slot 0 of ciphertext i and rotates it by -i [OFHE-UNVERIFIED: OpenFHE is not part of the reference tree]. */
+/* Galois element 5^index mod 2N of the row rotation by `index` (negative = to the right) */
+int piehip_rotation_galois(piehip_handle h, int32_t index, uint32_t *g);
+/* rotation keys (EvalSumKeyGen / EvalRotateKeyGen products, SimpleFHEPSIClient.cpp:80-89), BV layout as the
+ * relinearisation key: keys[nkeys][L][2][L][N], indices[nkeys] signed rotation amounts.  run() needs
+ * 2^r (r < ceil(log2 b)) and -1 .. -(b-1). */
+int piehip_load_rotation_keys(piehip_handle h, uint32_t nkeys, const int32_t *indices, const uint64_t *keys);
+/* constructor packing (FHEHIPPIE.cpp:23-59) for npie operators: slots[npie][K][b][E+1] (already in the bin
+ * order the caller's permutation vector chose), masks[npie][K][b] in [1, t-1]; encoded on the device.
+ * PIEHIP_EINVAL if b != E (the reference's invalid_argument). */
+int piehip_fhepie_load_table(piehip_handle h, uint32_t npie, uint32_t K, uint32_t b, uint32_t E, const int64_t *slots,
+                             const int64_t *masks);
+/* setIndex (FHEHIPPIE.hpp:45-48): idx[npie][K][2][L][N] */
+int piehip_fhepie_set_index(piehip_handle h, const uint64_t *idx);
+/* run() (FHEHIPPIE.cpp:61-77), synchronous; getResultList (FHEHIPPIE.hpp:40-43): out[npie][K][2][L][N] in hash
+ * function order (the caller applies its result permutation) */
+int piehip_fhepie_run(piehip_handle h);
+int piehip_fhepie_get_results(piehip_handle h, uint64_t *out);
+
 /* ---- client-side harness -----------------------------------------------------------------------------
  * Not part of the server hot path: the client role of src/Client/FHE/BatchedFHEPSIClient.cpp, needed to
  * produce the hot path's inputs, to read its outputs and to measure the end-to-end PSI wall-clock
@@ -150,6 +176,9 @@ int piehip_base_convert(piehip_handle h, int which, const uint64_t *in, uint32_t
 int piehip_client_keygen(piehip_handle h, uint64_t seed, uint64_t *sk);
 /* EvalMultKeyGen (BatchedFHEPSIClient.cpp:91): BV key, evk[L][2][L][N] */
 int piehip_client_relin_keygen(piehip_handle h, const uint64_t *sk, uint64_t seed, uint64_t *evk);
+/* EvalSumKeyGen / EvalRotateKeyGen (SimpleFHEPSIClient.cpp:80-89): BV key from s(X^g) to s for the row rotation
+ * by `index`, rk[L][2][L][N] */
+int piehip_client_rot_keygen(piehip_handle h, const uint64_t *sk, int32_t index, uint64_t seed, uint64_t *rk);
 /* MakePackedPlaintext + Encrypt(secretKey, .) (BatchedFHEPSIClient.cpp:155-156,161-168) of nct slot vectors
  * slots[nct][B]; seeds[nct] one sampler seed per ciphertext; out[nct][2][L][N] */
 int piehip_client_encrypt(piehip_handle h, const uint64_t *sk, const int64_t *slots, uint32_t nct, uint32_t B,

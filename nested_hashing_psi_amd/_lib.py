@@ -8,6 +8,7 @@ from .build import LIB_PATH
 u64p = C.POINTER(C.c_uint64)
 i64p = C.POINTER(C.c_int64)
 u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
 f64p = C.POINTER(C.c_double)
 
 NKERNELS = 12
@@ -48,6 +49,13 @@ SYMBOLS = {
     "piehip_encode": (C.c_int, [C.c_void_p, i64p, C.c_uint32, C.c_uint32, u64p]),
     "piehip_base_convert": (C.c_int, [C.c_void_p, C.c_int, u64p, C.c_uint32, u64p]),
     "piehip_bench_ntt": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, f64p]),
+    "piehip_rotation_galois": (C.c_int, [C.c_void_p, C.c_int32, u32p]),
+    "piehip_load_rotation_keys": (C.c_int, [C.c_void_p, C.c_uint32, i32p, u64p]),
+    "piehip_fhepie_load_table": (C.c_int, [C.c_void_p] + [C.c_uint32] * 4 + [i64p, i64p]),
+    "piehip_fhepie_set_index": (C.c_int, [C.c_void_p, u64p]),
+    "piehip_fhepie_run": (C.c_int, [C.c_void_p]),
+    "piehip_fhepie_get_results": (C.c_int, [C.c_void_p, u64p]),
+    "piehip_client_rot_keygen": (C.c_int, [C.c_void_p, u64p, C.c_int32, C.c_uint64, u64p]),
     "piehip_client_keygen": (C.c_int, [C.c_void_p, C.c_uint64, u64p]),
     "piehip_client_relin_keygen": (C.c_int, [C.c_void_p, u64p, C.c_uint64, u64p]),
     "piehip_client_encrypt": (C.c_int, [C.c_void_p, u64p, i64p, C.c_uint32, C.c_uint32, u64p, u64p]),

@@ -34,6 +34,21 @@ class BatchedFHEPSIClient:
                                                 self.evalMultKey.ctypes.data_as(u64p)))
         return self.evalMultKey
 
+    # -- EvalSumKeyGen + EvalRotateKeyGen of the rotation-based sibling (SimpleFHEPSIClient.cpp:80-89): keys for the
+    #    rotations 2^r (r < ceil(log2 b)) and -1 .. -(b-1) that FHEHIPPIE::run needs
+    def rotationKeyGen(self, nbins, seedBase=50):
+        cc = self.cc
+        R = 0
+        while (1 << R) < nbins:
+            R += 1
+        rots = [1 << r for r in range(R)] + [-i for i in range(1, nbins)]
+        keys = {}
+        for i, r in enumerate(rots):
+            rk = np.zeros((cc.L, 2, cc.L, cc.N), dtype=np.uint64)
+            _check(lib().piehip_client_rot_keygen(cc._h, self.sk.ctypes.data_as(u64p), r, seedBase + i, rk.ctypes.data_as(u64p)))
+            keys[r] = rk
+        return keys
+
     # -- client Cuckoo table: CuckooHashTable(hash, e, k, startingHashId 0, stash 0, multi, 1 layer)
     #    (BatchedFHEPSIClient.cpp:97-99, insertAll at :109; insert at CuckooHashTable.cpp:72-114)
     def _hash_client_set(self, items):

@@ -536,12 +536,14 @@ void launch_digits(const DevConsts *dc, u32 N, u32 L, const u64 *d2, size_t stri
 template <bool MAD>
 __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, const u64 *__restrict__ d01,
                                                         size_t stride01, const u64 *__restrict__ dig,
-                                                        const u64 *__restrict__ key, const u64 *__restrict__ mask,
-                                                        u64 *__restrict__ out, const u32 *__restrict__ out_map)
+                                                        const u64 *__restrict__ key0, const u64 *__restrict__ mask,
+                                                        u64 *__restrict__ out, const u32 *__restrict__ out_map,
+                                                        size_t key_stride, u32 key_group)
 {
     const u32 n = 2 * (blockIdx.x * TPB + threadIdx.x);
     if (n >= N) return;
     const u32 j = blockIdx.y, bin = blockIdx.z;
+    const u64 *key = key0 + (size_t)(bin % key_group) * key_stride;  // one key per position in a group (EvalMerge)
     const Mod m = dc->mod[j];
     const size_t LN = (size_t)L * N;
     U128 acc[2][2];
@@ -593,13 +595,16 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restr
     }
 }
 void launch_relin_mac(const DevConsts *dc, u32 N, u32 L, const u64 *d01, size_t stride01, const u64 *dig, const u64 *key,
-                      const u64 *mask, u64 *out, u32 nb, hipStream_t st, const u32 *out_map)
+                      const u64 *mask, u64 *out, u32 nb, hipStream_t st, const u32 *out_map, size_t key_stride, u32 key_group)
 {
     dim3 grid((N / 2 + TPB - 1) / TPB, L, nb);
+    if (!key_group) key_group = 1;
     if (g_small_moduli)
-        hipLaunchKernelGGL(relin_mac_kernel<true>, grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map);
+        hipLaunchKernelGGL(relin_mac_kernel<true>, grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map,
+                           key_stride, key_group);
     else
-        hipLaunchKernelGGL(relin_mac_kernel<false>, grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map);
+        hipLaunchKernelGGL(relin_mac_kernel<false>, grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map,
+                           key_stride, key_group);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -651,6 +656,83 @@ void launch_permute(u32 N, const u64 *in, const u32 *map, u64 *out, u32 nrows, h
 {
     dim3 grid((N + TPB - 1) / TPB, nrows);
     hipLaunchKernelGGL(permute_kernel, grid, dim3(TPB), 0, st, N, in, map, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rotation-based PIE (FHEHIPPIE.cpp:61-77): EvalInnerProduct = ct x pt + log2 rotate-and-add steps, EvalMerge =
+// mask slot 0, rotate ciphertext i by -i, add.  All steps batched over (PIE, bin).
+// ---------------------------------------------------------------------------------------------
+// out[i] = x[i / group] (.) pt[i / group][i % group]      (one index ciphertext against a group of plaintexts)
+__global__ void __launch_bounds__(TPB) bcast_mul_plain_kernel(const DevConsts *dc, u32 N, u32 L, const u64 *__restrict__ x,
+                                                              size_t xs, u32 group, const u64 *__restrict__ pt, size_t ps_outer,
+                                                              size_t ps_inner, u64 *__restrict__ out)
+{
+    const u32 n = blockIdx.x * TPB + threadIdx.x;
+    if (n >= N) return;
+    const u32 l = blockIdx.y % L, i = blockIdx.z, g = i / group, r = i % group;
+    const size_t LN = (size_t)L * N;
+    const size_t o = (size_t)blockIdx.y * N + n;
+    out[(size_t)i * 2 * LN + o] = mulmod(x[(size_t)g * xs + o], pt[(size_t)g * ps_outer + (size_t)r * ps_inner + (size_t)l * N + n], dc->mod[l]);
+}
+void launch_bcast_mul_plain(const DevConsts *dc, u32 N, u32 L, const u64 *x, size_t xs, u32 group, const u64 *pt, size_t ps_outer,
+                            size_t ps_inner, u64 *out, u32 nct, hipStream_t st)
+{
+    dim3 grid((N + TPB - 1) / TPB, 2 * L, nct);
+    hipLaunchKernelGGL(bcast_mul_plain_kernel, grid, dim3(TPB), 0, st, dc, N, L, x, xs, group, pt, ps_outer, ps_inner, out);
+}
+// Automorphism of ciphertext i with the EVALUATION index map maps[i % map_group]:
+//   d01[i] = (acc ? x.c0 : 0) + x.c0 o map,  (acc ? x.c1 : 0)       (stays in EVALUATION format)
+//   d2[i]  = x.c1 o map                                              (goes through the key switch)
+// identity_first: position 0 of every group is not rotated (EvalMerge's first term): d01 = x, d2 = 0.
+__global__ void __launch_bounds__(TPB) rot_prepare_kernel(const DevConsts *dc, u32 N, u32 L, const u64 *__restrict__ x,
+                                                          const u32 *__restrict__ maps, u32 map_group, u32 acc, u32 identity_first,
+                                                          u64 *__restrict__ d01, u64 *__restrict__ d2)
+{
+    const u32 p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= N) return;
+    const u32 l = blockIdx.y, i = blockIdx.z, r = i % map_group;
+    const size_t LN = (size_t)L * N;
+    const u64 *c0 = x + (size_t)i * 2 * LN + (size_t)l * N, *c1 = c0 + LN;
+    u64 *o0 = d01 + (size_t)i * 2 * LN + (size_t)l * N, *o1 = o0 + LN, *o2 = d2 + (size_t)i * LN + (size_t)l * N;
+    if (identity_first && r == 0) {
+        o0[p] = c0[p];
+        o1[p] = c1[p];
+        o2[p] = 0;
+        return;
+    }
+    const u32 s = maps[(size_t)r * N + p];
+    const u64 q = dc->mod[l].q;
+    o0[p] = acc ? addmod(c0[p], c0[s], q) : c0[s];
+    o1[p] = acc ? c1[p] : 0;
+    o2[p] = c1[s];
+}
+void launch_rot_prepare(const DevConsts *dc, u32 N, u32 L, const u64 *x, const u32 *maps, u32 map_group, bool acc, bool identity_first,
+                        u64 *d01, u64 *d2, u32 nct, hipStream_t st)
+{
+    dim3 grid((N + TPB - 1) / TPB, L, nct);
+    hipLaunchKernelGGL(rot_prepare_kernel, grid, dim3(TPB), 0, st, dc, N, L, x, maps, map_group ? map_group : 1u, acc ? 1u : 0u,
+                       identity_first ? 1u : 0u, d01, d2);
+}
+// out[g] = (sum_{r < group} x[g * group + r]) (.) pt[g]
+__global__ void __launch_bounds__(TPB) sum_mul_plain_kernel(const DevConsts *dc, u32 N, u32 L, const u64 *__restrict__ x, u32 group,
+                                                            const u64 *__restrict__ pt, size_t pt_stride, u64 *__restrict__ out,
+                                                            size_t out_stride)
+{
+    const u32 n = blockIdx.x * TPB + threadIdx.x;
+    if (n >= N) return;
+    const u32 l = blockIdx.y % L, g = blockIdx.z;
+    const size_t LN = (size_t)L * N;
+    const size_t o = (size_t)blockIdx.y * N + n;
+    const Mod m = dc->mod[l];
+    u64 s = 0;
+    for (u32 r = 0; r < group; r++) s = addmod(s, x[((size_t)g * group + r) * 2 * LN + o], m.q);
+    out[(size_t)g * out_stride + o] = mulmod(s, pt[(size_t)g * pt_stride + (size_t)l * N + n], m);
+}
+void launch_sum_mul_plain(const DevConsts *dc, u32 N, u32 L, const u64 *x, u32 group, const u64 *pt, size_t pt_stride, u64 *out,
+                          size_t out_stride, u32 ngroups, hipStream_t st)
+{
+    dim3 grid((N + TPB - 1) / TPB, 2 * L, ngroups);
+    hipLaunchKernelGGL(sum_mul_plain_kernel, grid, dim3(TPB), 0, st, dc, N, L, x, group, pt, pt_stride, out, out_stride);
 }
 
 // ---------------------------------------------------------------------------------------------

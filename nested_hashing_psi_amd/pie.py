@@ -14,7 +14,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import NKERNELS, f64p, i64p, lib, u32p, u64p
+from ._lib import NKERNELS, f64p, i32p, i64p, lib, u32p, u64p
 
 EINVAL, ESTATE, EHIP, ENOMEM, EHASH = -1, -2, -3, -4, -5
 
@@ -155,6 +155,20 @@ class PieContext:
         assert a.shape == (self.L, 2, self.L, self.N)
         _check(lib().piehip_load_relin_key(self._h, ap))
 
+    def rotation_galois(self, index):
+        """Galois element 5^index mod 2N of the row rotation by `index` (EvalAtIndex convention: > 0 rotates left)"""
+        g = C.c_uint32()
+        _check(lib().piehip_rotation_galois(self._h, int(index), C.byref(g)))
+        return int(g.value)
+
+    def load_rotation_keys(self, keys):
+        """keys: {rotation index: [L][2][L][N]} -- the EvalSum / EvalAtIndex key maps the server receives
+        (reference SimpleFHEPSIServer.cpp receives them with the context)"""
+        idx = np.array(sorted(keys), dtype=np.int32)
+        ka = np.ascontiguousarray(np.stack([np.asarray(keys[int(i)], dtype=np.uint64) for i in idx]))
+        assert ka.shape[1:] == (self.L, 2, self.L, self.N)
+        _check(lib().piehip_load_rotation_keys(self._h, len(idx), idx.ctypes.data_as(i32p), ka.ctypes.data_as(u64p)))
+
     # -- measurement
     def bench_ntt(self, nlimbs, mod_count=None, inverse=False, iters=20):
         ms = C.c_double()
@@ -270,3 +284,59 @@ class BatchedFHEHIPPIE:
         p = C.c_void_p()
         _check(lib().piehip_results_device(self.cc._h, C.byref(p)))
         return p.value
+
+
+class FHEHIPPIE:
+    """Mirror of the rotation-based operator (reference FHEHIPPIE.hpp:18-49, FHEHIPPIE.cpp), batched over `npie`
+    operators (the reference holds one per client slot in an FHEHIPPIECollection, PIECollection.hpp).
+
+    cuckooTable: [npie][K][b][E] (or [K][b][E]) table cells, b == E; rotation keys must be loaded into the context
+    (PieContext.load_rotation_keys).  The constructor hides the bin order with one permutation per operator
+    (permVec2, FHEHIPPIE.cpp:28,50) and draws the masks (FHEHIPPIE.cpp:52); getResultList applies the result
+    permutation (permutationVector, FHEHIPPIE.hpp:30-34, FHEHIPPIE.cpp:76).  Both come from a seeded numpy
+    generator here (the reference uses std::random_device); pass perm_seed=None to keep the natural order.
+    """
+
+    def __init__(self, cryptoContext, cuckooTable, stashSize=0, perm_seed=5, mask_seed=6, masks=None):
+        if stashSize != 0:
+            raise ValueError("Error, FHE PIE does not support a stash (yet).")
+        self.cc = cryptoContext
+        tbl = np.asarray(cuckooTable, dtype=np.uint64)
+        self._single = tbl.ndim == 3
+        if self._single:
+            tbl = tbl[None]
+        self.npie, self.K, self.b, self.E = tbl.shape
+        if self.b != self.E:
+            raise ValueError("Error, for FHE PIE the size of a cuckoo bin has to be equal than the number of bins per hash function.")
+        rng = np.random.default_rng(perm_seed) if perm_seed is not None else None
+        self.permVec2 = np.stack([rng.permutation(self.b) if rng is not None else np.arange(self.b) for _ in range(self.npie)])
+        self.permutationVector = np.stack([rng.permutation(self.K) if rng is not None else np.arange(self.K) for _ in range(self.npie)])
+        slots = np.ones((self.npie, self.K, self.b, self.E + 1), dtype=np.int64)  # last slot: exponent of the "minus client" element
+        for i in range(self.npie):
+            slots[i, :, self.permVec2[i], :self.E] = tbl[i].astype(np.int64).transpose(1, 0, 2)
+        if masks is None:
+            masks = np.random.default_rng(mask_seed).integers(1, self.cc.t, size=(self.npie, self.K, self.b), dtype=np.int64)
+        self.masks = np.ascontiguousarray(masks, dtype=np.int64).reshape(self.npie, self.K, self.b)
+        self.slots = np.ascontiguousarray(slots)
+        _check(lib().piehip_fhepie_load_table(self.cc._h, self.npie, self.K, self.b, self.E, self.slots.ctypes.data_as(i64p),
+                                              self.masks.ctypes.data_as(i64p)))
+
+    def setIndex(self, indexMatrix):
+        a, ap = _u64(indexMatrix)
+        if self._single and a.ndim == 4:
+            a = a[None]
+        if a.shape != (self.npie, self.K, 2, self.cc.L, self.cc.N):
+            raise ValueError("index matrix must be one ciphertext per hash function")
+        a, ap = _u64(a)
+        _check(lib().piehip_fhepie_set_index(self.cc._h, ap))
+
+    def run(self):
+        _check(lib().piehip_fhepie_run(self.cc._h))
+
+    def getResultList(self):
+        out = np.zeros((self.npie, self.K, 2, self.cc.L, self.cc.N), dtype=np.uint64)
+        _check(lib().piehip_fhepie_get_results(self.cc._h, out.ctypes.data_as(u64p)))
+        shuffled = np.empty_like(out)
+        for i in range(self.npie):
+            shuffled[i, self.permutationVector[i]] = out[i]
+        return shuffled[0] if self._single else shuffled

@@ -337,3 +337,42 @@ def client_scan(ctab, decrypted):
     out = np.zeros(k * e, dtype=np.uint64)
     n = lib().ph_client_scan(_p(ctab), k, e, b, _p(dec, i64p), _p(out))
     return out[:n].copy()
+
+
+def fhe_pie_run(o, idx, slots, masks, rot_keys):
+    """FHEHIPPIE::run() for one operator (reference FHEHIPPIE.cpp:61-77), composed from the C primitives.
+
+    idx [K][2][L][N] index ciphertexts, slots [K][b][E+1] packed rows (FHEHIPPIE.cpp:41-51), masks [K][b],
+    rot_keys {rotation index: BV key}.  EvalInnerProduct(ct, pt, b) = EvalMult then ceil(log2 b) steps of
+    ct += rotate(ct, 2^r); EvalMerge masks slot 0 of ciphertext i and rotates it by -i [OFHE-UNVERIFIED].
+    Returns [K][2][L][N] in hash-function order (the caller applies permutationVector).
+    """
+    K, nb, _ = slots.shape
+    R = 0
+    while (1 << R) < nb:
+        R += 1
+    e0 = o.encode_eval(np.array([1], dtype=np.int64))
+    out = []
+    for hf in range(K):
+        evals = []
+        for bn in range(nb):
+            ct = o.mul_plain(idx[hf], o.encode_eval(slots[hf, bn]))
+            for r in range(R):
+                ct = o.add(ct, o.automorph(ct, o.rot_index(1 << r), rot_keys[1 << r]))
+            evals.append(ct)
+        merged = o.mul_plain(evals[0], e0)
+        for i in range(1, nb):
+            merged = o.add(merged, o.automorph(o.mul_plain(evals[i], e0), o.rot_index(-i), rot_keys[-i]))
+        out.append(o.mul_plain(merged, o.encode_eval(masks[hf])))
+    return np.stack(out)
+
+
+def fhe_pie_index_vectors(tab, x, k, K, E):
+    """Index vectors of the non-batched client for one element (reference SimpleFHEPSIClient.cpp:124-154):
+    one-hot at hash_{k+hf}(x) mod E, last slot -x; the dummy element 1 gets an all-zero one-hot part."""
+    v = np.zeros((K, E + 1), dtype=np.int64)
+    for hf in range(K):
+        if x != 1:
+            v[hf, tab.hash(x, k + hf) % E] = 1
+        v[hf, E] = -int(x)
+    return v

@@ -361,3 +361,83 @@ def test_end_to_end_psi_all_on_device(ob, pie):
     found = cl.extractIntersection(srv.getResultList())
     assert sorted(int(v) for v in found) == sorted(int(v) for v in inter)
     cc.close()
+
+
+# ---- rotation-based sibling operator (FHEHIPPIE) ----------------------------------------------
+@pytest.mark.parametrize("N,L,t,K,E", [(2048, 3, T16, 3, 12), (4096, 3, T32, 2, 10), (16384, 4, T32, 2, 5)])
+def test_fhepie_bit_exact_and_semantics(ob, pie, N, L, t, K, E):
+    """piehip_fhepie_run == the oracle's restatement of FHEHIPPIE::run (FHEHIPPIE.cpp:61-77), bit for bit; one
+    zero slot among the K results when the element is in the table (tests/TestFHEPIE.cpp:125-137)"""
+    from tests.test_oracle_pie import fhepie_case
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    sk = o.keygen(1)
+    c = fhepie_case(ob, o, sk, t, K, E, 10 * E, True)
+    for r in c["keys"]:
+        assert cc.rotation_galois(r) == o.rot_index(r)
+    cc.load_rotation_keys(c["keys"])
+    op = pie.FHEHIPPIE(cc, c["tbl"], perm_seed=None, masks=c["masks"])
+    assert (op.slots[0] == c["slots"]).all()
+    op.setIndex(c["idx"])
+    op.run()
+    got = op.getResultList()
+    want = ob.fhe_pie_run(o, c["idx"], c["slots"], c["masks"], c["keys"])
+    assert (got == want).all()
+    zeros = sum(int((o.decrypt_slots(sk, got[hf], E)[0] == 0).sum()) for hf in range(K))
+    assert zeros == 1
+    cc.close()
+
+
+def test_fhepie_collection_with_client_harness(ob, pie):
+    """a collection of operators (one per client slot, PIECollection.hpp) in one batch, keys and ciphertexts from the
+    product's client harness, bin and result permutations on: exactly the present elements produce a zero slot"""
+    from nested_hashing_psi_amd.client import BatchedFHEPSIClient
+    from tests.test_oracle_pie import distinct_items
+    N, L, t, K, E, npie = 4096, 3, T32, 2, 10, 4
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    cl = BatchedFHEPSIClient(cc, 1, 1, K, E, E)
+    cl.runSetUpPhase(keySeed=21, evalKeySeed=22)
+    keys = cl.rotationKeyGen(E, seedBase=50)
+    sk = o.keygen(21)
+    R = int(np.ceil(np.log2(E)))
+    rots = [1 << r for r in range(R)] + [-i for i in range(1, E)]
+    for i, r in enumerate(rots):  # the harness' keys are the oracle's keys
+        assert (keys[r] == o.rot_keygen(sk, o.rot_index(r), 50 + i)).all()
+    cc.load_rotation_keys(keys)
+    rng = np.random.default_rng(77)
+    tab = ob.Tabulation(987654321, K + 1)
+    tables, index, present = [], [], [True, False, True, False]
+    for i in range(npie):
+        items = distinct_items(rng, t, 61)
+        tables.append(ob.hct_build(tab, items[:60], 1, 1, K, E, E, evict_seed=3 + i)[0, 0])
+        x = int(items[7 + i]) if present[i] else int(items[60])
+        index.append(ob.fhe_pie_index_vectors(tab, x, 1, K, E))
+    index = np.stack(index)
+    idx = cl._encrypt(index.reshape(npie * K, E + 1), 300 + np.arange(npie * K)).reshape(npie, K, 2, L, N)
+    op = pie.FHEHIPPIE(cc, np.stack(tables), perm_seed=5, mask_seed=6)
+    op.setIndex(idx)
+    op.run()
+    res = op.getResultList()
+    dec = cl.decrypt(res.reshape(npie * K, 2, L, N), nslots=E).reshape(npie, K, E)
+    for i in range(npie):
+        assert int((dec[i] == 0).sum()) == (1 if present[i] else 0)
+    # the oracle agrees bit for bit on one operator of the batch (undo the result permutation)
+    want = ob.fhe_pie_run(o, idx[2], op.slots[2], op.masks[2], keys)
+    assert (res[2][op.permutationVector[2]] == want).all()
+    cc.close()
+
+
+def test_fhepie_error_behaviour(ob, pie):
+    cc = pie.PieContext(1024, 2, T16)
+    with pytest.raises(ValueError, match="cuckoo bin"):       # FHEHIPPIE.cpp:13-16
+        pie.FHEHIPPIE(cc, np.ones((2, 4, 5), dtype=np.uint64))
+    with pytest.raises(ValueError, match="stash"):            # FHEHIPPIE.cpp:17-20
+        pie.FHEHIPPIE(cc, np.ones((2, 4, 4), dtype=np.uint64), stashSize=1)
+    op = pie.FHEHIPPIE(cc, np.ones((2, 4, 4), dtype=np.uint64))
+    op.setIndex(np.zeros((2, 2, 2, 1024), dtype=np.uint64))
+    with pytest.raises(RuntimeError, match="key for rotation"):
+        op.run()
+    with pytest.raises(ValueError):
+        op.setIndex(np.zeros((3, 2, 2, 1024), dtype=np.uint64))
+    cc.close()

@@ -168,3 +168,47 @@ def test_tabulation_hash_is_std_mt19937(ob):
     for i in range(16):
         want ^= draws[256 * i + ((x >> (8 * i)) & 0xFF if i < 8 else 0)]
     assert tab.hash(x, 0) == want
+
+
+# ---- KAT-3: rotation-based sibling operator ---------------------------------------------------------------
+def fhepie_case(ob, o, sk, t, K, E, nitems, present, hash_seed=424242, key_seed=50):
+    """tests/TestFHEPIE.cpp:52-123 at a reduced shape: flat blocked Cuckoo table [K][b=E][E], one client element,
+    hand-built index vectors (one-hot at hash_hf(x) mod E, last slot -x), EvalSum + EvalRotate keys"""
+    rng = np.random.default_rng(20240607)
+    items = distinct_items(rng, t, nitems + 1)
+    table_items, absent = items[:nitems], int(items[nitems])
+    tab = ob.Tabulation(hash_seed, K + 1)
+    # one sub-table of the nested structure: [K][b][E] with the inner hash ids 1..K (k = 1 outer function, e = 1)
+    tbl = ob.hct_build(tab, table_items, 1, 1, K, E, E, evict_seed=3)[0, 0]
+    elem = int(table_items[nitems // 2]) if present else absent
+    index = ob.fhe_pie_index_vectors(tab, elem, 1, K, E)
+    idx = np.stack([o.encrypt_slots(sk, index[hf], 70 + hf) for hf in range(K)])
+    R = int(np.ceil(np.log2(E)))
+    rots = [1 << r for r in range(R)] + [-i for i in range(1, E)]
+    keys = {r: o.rot_keygen(sk, o.rot_index(r), key_seed + i) for i, r in enumerate(rots)}
+    slots = np.ones((K, E, E + 1), dtype=np.int64)
+    slots[:, :, :E] = tbl.astype(np.int64)
+    masks = np.random.default_rng(6).integers(1, t, size=(K, E), dtype=np.int64)
+    return dict(tbl=tbl, elem=elem, idx=idx, keys=keys, slots=slots, masks=masks, tab=tab)
+
+
+@pytest.mark.parametrize("present", [True, False])
+def test_kat3_rotation_based_pie(ob, present):
+    """FHEHIPPIE::run (FHEHIPPIE.cpp:61-77): exactly one zero among the first b slots of the K results when the
+    element is in the table ("Matches", TestFHEPIE.cpp:125-137), none otherwise"""
+    N, L, t, K, E = 2048, 3, T16, 3, 12
+    o = ob.Oracle(N, L, t)
+    sk = o.keygen(1)
+    c = fhepie_case(ob, o, sk, t, K, E, 150, present)
+    res = ob.fhe_pie_run(o, c["idx"], c["slots"], c["masks"], c["keys"])
+    zeros = 0
+    for hf in range(K):
+        dec, budget = o.decrypt_slots(sk, res[hf], E)
+        assert budget > 0
+        # slot i = mask_i * (T[hf][i][h(x)] - x)
+        hi = c["tab"].hash(c["elem"], 1 + hf) % E
+        want = [(int(c["masks"][hf, i]) * ((int(c["tbl"][hf, i, hi]) - c["elem"]) % t)) % t for i in range(E)]
+        got = [int(v) % t for v in dec]
+        assert got == want
+        zeros += int((dec == 0).sum())
+    assert zeros == (1 if present else 0)
