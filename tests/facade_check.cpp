@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../nested_hashing_psi_amd/host/BatchedFHEHIPPIE.hpp"
+#include "../nested_hashing_psi_amd/host/FHEHIPPIE.hpp"
 
 int main()
 {
@@ -39,6 +40,30 @@ int main()
         pie.setIndex(std::move(idx));
         pie.run();
         std::printf("facade ok: %zu result ciphertexts\n", pie.getResultList().size());
+        // the rotation-based sibling (FHEHIPPIE.hpp): argument checks, then the reference call order
+        CuckooTableView cv;
+        cv.numberOfHashFunctions = 2, cv.binSize = 4, cv.eachTableSize = 4;
+        std::vector<uint64_t> ctab(2 * 4 * 4);
+        for (size_t i = 0; i < ctab.size(); i++) ctab[i] = (i * 104729u) % 65536u + 1;
+        cv.table = ctab.data();
+        threw = false;
+        try {
+            CuckooTableView bad = cv;
+            bad.binSize = 3;
+            FHEHIPPIE p2(cc, {bad});
+        } catch (const std::invalid_argument &) {
+            threw = true;
+        }
+        if (!threw) return 3;
+        std::vector<int32_t> rots = {1, 2, -1, -2, -3};
+        std::vector<uint64_t> rk(rots.size() * 2 * 2 * 2 * 1024, 1);
+        setRotationKeys(cc, rots, rk.data());
+        FHEHIPPIE rot(cc, {cv, cv});
+        std::vector<LimbCt> ridx(2 * 2);
+        for (auto &c : ridx) c.limbs.assign(ct, 7);
+        rot.setIndex(std::move(ridx));
+        rot.run();
+        std::printf("rotation facade ok: %zu result ciphertexts\n", rot.getResultList().size());
         return 0;
     } catch (const std::runtime_error &e) {
         std::printf("no device: %s\n", e.what());
