@@ -182,9 +182,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end PSI wall-clock leg")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams run() spreads the bin layers over (0 = library default, 1 = serial: every kernel alone on the GPU)")
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: run the RCCL gather path even with one rank (launch under torch.distributed.run)")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: libraries that print banners to fd 1 (RCCL's version block) go to stderr
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     from nested_hashing_psi_amd import pie, shard
@@ -236,6 +243,7 @@ def main():
         op = pie.BatchedFHEHIPPIE(cc, slots=slots, mask_slots=mask_slots)  # packed + NTT'd on the device
         op.setIndexDevice(idx.data_ptr())
         op.setMinusCompareElementDevice(minus.data_ptr())
+    cc.set_run_streams(args.streams)
     ct_words = 2 * L * N
     gathered = my_out = works = None
     if use_dist:
@@ -248,15 +256,19 @@ def main():
     state = {"i": 0}
 
     def step():
-        if op is not None:
-            op.run(sync=False)
-        if use_dist:
+        if not use_dist:
+            if op is not None:
+                op.run(sync=False)
+            return
+        if True:
             s_ = state["i"] & 1
             state["i"] += 1
             if works[s_] is not None:
                 works[s_].wait()                              # buffer set s_ is free again (query i-2 gathered)
             if op is not None:
-                op.copyResultsToDevice(my_out[s_].data_ptr())   # same stream as run(): ordered after it
+                # results go straight into the gather buffer; the kernel that writes them waits for the line above
+                op.run(sync=False, into=my_out[s_].data_ptr())
+                op.join()                                     # this stream (and the gather behind it) waits for the run
             # the path's only collective: RCCL all-gather of the result ciphertexts
             works[s_] = dist.all_gather_into_tensor(gathered[s_], my_out[s_], async_op=True)
 
@@ -288,10 +300,13 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
 
-    # per-kernel times of the same run(), HIP events on the launch stream (separate, untimed passes)
+    # per-kernel times of the same run(), HIP events on the launch stream (separate, untimed passes).  These passes are
+    # serial (one stream): with the default two queues a kernel shares the chip with the other queue's kernels and its
+    # duration says nothing about the kernel itself.  `bench.py --streams 1` runs the timed region the same way.
     roofline = None
     kernels = {}
     if op is not None and rank == 0:
+        cc.set_run_streams(1)
         cc.set_profiling(True)
         agg = {}
         for _ in range(max(1, args.profile_steps)):
@@ -301,6 +316,7 @@ def main():
                 for key in a:
                     a[key] += rec[key]
         cc.set_profiling(False)
+        cc.set_run_streams(args.streams)
         for name, a in agg.items():
             kernels[name] = dict(launches_per_step=a["launches"] / args.profile_steps, us_per_step=1e3 * a["ms"] / args.profile_steps,
                                  alg_GBps=a["alg_bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else None)
@@ -312,7 +328,9 @@ def main():
             roofline = {"kernel": "ntt (forward+inverse, LDS-resident limb)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config),
                         "avg_launch_us": 1e3 * ntt_ms / ntt_launch, "alg_bytes_per_launch": ntt_bytes / ntt_launch,
-                        "launches_per_step": ntt_launch / args.profile_steps}
+                        "launches_per_step": ntt_launch / args.profile_steps,
+                        "measured": "HIP events around every launch, %d serial passes of run() (one stream; the timed region uses %s)"
+                                    % (args.profile_steps, "the library default of 2 queues" if args.streams == 0 else "%d" % args.streams)}
 
     if rank == 0:
         value = b_total / (ms_per_step * 1e-3)
@@ -326,7 +344,7 @@ def main():
                                       b_local, b_local * K * E, b_local * (K - 1), b_local),
                        "result_ciphertexts_per_step": b_total, "parallelism": "bins%d" % world,
                        "collective": "rccl all_gather of results" if use_dist else "none"},
-            "mac_per_s": b_total * K * E / (ms_per_step * 1e-3),
+            "mac_per_s": b_total * K * E / (ms_per_step * 1e-3), "run_streams": args.streams if args.streams else 2,
             "roofline": roofline, "kernels": kernels,
         }
         if not args.no_e2e and world == 1:
@@ -336,7 +354,11 @@ def main():
             line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]
             if "e2e_psi" in line:
                 line["e2e_speedup_vs_cpu_1core"] = line["cpu_baseline"]["e2e_psi_cpu_s"]["total_s"] / line["e2e_psi"]["total_s"]
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(line))
+        sys.stdout.flush()
+        os.dup2(2, 1)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

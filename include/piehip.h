@@ -110,7 +110,19 @@ int piehip_set_minus_device(piehip_handle h, const void *d_minus);
 /* run() (BatchedFHEHIPPIE.cpp:88-129): enqueue the whole evaluation on the handle's stream.
  * Asynchronous; piehip_sync() or piehip_get_results() waits for it. */
 int piehip_run(piehip_handle h);
+/* the same, with the result ciphertexts written straight into caller-owned HBM d_results[b][2][L][N] (e.g. the RCCL
+ * gather buffer) instead of the handle's result buffer */
+int piehip_run_into(piehip_handle h, void *d_results);
+/* Stream order.  run() works on the handle's own queues (piehip_set_run_streams); it waits for the handle's stream
+ * where it must (new inputs; the result buffer), and the handle's stream waits for the run in the next call of any
+ * other entry point -- piehip_join() does only that, piehip_sync() also blocks the host.  Work queued on the handle's
+ * stream after such a call sees the results; consecutive run() calls pipeline. */
+int piehip_join(piehip_handle h);
 int piehip_sync(piehip_handle h);
+/* run() spreads the (independent) bin layers over up to n HIP streams of the handle so that the partial workgroup rounds of
+ * one group's launches are filled by another group's; n = 1 serialises everything on the handle's stream (per-kernel
+ * timing), 0 = the default (2).  The results are complete on the handle's stream either way. */
+int piehip_set_run_streams(piehip_handle h, uint32_t n);
 /* getResultList (BatchedFHEHIPPIE.hpp:35-38): out[b][2][L][N] */
 int piehip_get_results(piehip_handle h, uint64_t *out);
 /* device address of the result buffer [b][2][L][N] (valid until destroy); for the RCCL gather */

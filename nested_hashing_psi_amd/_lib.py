@@ -38,6 +38,9 @@ SYMBOLS = {
     "piehip_set_minus_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "piehip_run": (C.c_int, [C.c_void_p]),
     "piehip_sync": (C.c_int, [C.c_void_p]),
+    "piehip_join": (C.c_int, [C.c_void_p]),
+    "piehip_run_into": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "piehip_set_run_streams": (C.c_int, [C.c_void_p, C.c_uint32]),
     "piehip_get_results": (C.c_int, [C.c_void_p, u64p]),
     "piehip_results_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "piehip_copy_results_device": (C.c_int, [C.c_void_p, C.c_void_p]),

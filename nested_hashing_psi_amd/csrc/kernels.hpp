@@ -25,9 +25,21 @@ struct NttPlan {
 // (replaces DCRTPoly::SetFormat under BatchedFHEHIPPIE.cpp:123)
 void build_twc_table(const u64 *nat_pairs, u32 logN, u32 s0, std::vector<u64> &out);
 u32 ntt_fast_s0(u32 logN);  // log2 slices per limb the fast kernel would use, or ~0u if it does not apply
+// Optional extras of the register-blocked kernel (ciphertext multiplication, kernels_ntt_fast.hip):
+//   inverse, standard order in:  limbs [nb][copy_K][2][copy_L]; the lane-ordered EVALUATION input of operand 0 of every
+//                                bin is also written to the Q limbs of copy_out[nb][4][copy_M][N] (slots 0, 1)
+//   forward:                     nlimbs counts a compact enumeration of [nb][4][skip_M] that omits limbs < skip_L of
+//                                slots 0 and 1 (they already hold EVALUATION data)
+struct NttExtra {
+    u64 *copy_out = nullptr;
+    u32 copy_K = 1, copy_L = 1, copy_M = 1;
+    u32 skip_L = 0, skip_M = 0;
+};
 bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
                      u32 mod_count, bool inverse, bool sigma, u32 num_cus, hipStream_t st, const u64 *lift_src = nullptr,
-                     u32 lift_L = 0, u32 sigma_split = 0);
+                     u32 lift_L = 0, u32 sigma_split = 0, const NttExtra *ex = nullptr);
+// true when launch_ntt(.., folded) / launch_ntt(..) for this plan goes to the register-blocked kernel and honours NttExtra
+bool ntt_supports_extra(const NttPlan &pl, bool folded);
 // forward transform of the BV digits with the digit lift fused into the load (no digits kernel):
 // d2[nb][L][N] COEFFICIENT -> dig[nb][L(i)][L(j)][N] EVALUATION.  Returns false if the register-blocked
 // kernel does not cover this ring dimension as one slice (callers then use launch_digits + launch_ntt).
@@ -41,12 +53,14 @@ void ntt_sigma_inverse_map(u32 logN, u32 s0, std::vector<u32> &map);  // s0 = ~0
 // folded: the outermost stage is NOT done here (the caller's neighbouring kernels apply it, kernels_pie.hip
 // "Outer-stage folding"); the limb is transformed as two independent half-size slices.  Requires pl.twc_fold.
 void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, hipStream_t st,
-                bool sigma = false, bool folded = false);
+                bool sigma = false, bool folded = false, const NttExtra *ex = nullptr);
 
 // Stage A: acc[b][K][2][L][N] = sum_j idx[h][j] (.) db[h][beta][j] + minus    (BatchedFHEHIPPIE.cpp:101-116)
 // small_moduli: every RNS modulus is < 2^60 (enables the v_mad_u64_u32 column-accumulator kernel)
+// bstride: bin-layer count of the database array db[K][bstride][E][L][N] when only b <= bstride layers (starting at the
+// layer db points to) are evaluated; 0 = b
 void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
-                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli);
+                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride = 0);
 
 // (process-wide switch, set from the context before its launches: all Q and P moduli are < 2^60, which lets the
 // base-conversion kernels use the carry-free v_mad_u64_u32 column accumulators)
@@ -55,9 +69,10 @@ void set_small_moduli(bool v);
 // Base conversions, COEFFICIENT format.  Polynomial (o, c), o < n_outer, c < 2,
 // is read at in + o*in_stride_outer + c*in_stride_inner ([L][N] limbs) and written to
 // out + ((o*out_polys + out_slot + c)*M)*N ([M][N] limbs).
+// skip_q: leave the Q limbs of the output alone (they already hold the operand's EVALUATION form, see NttExtra)
 void launch_expand_q_to_qp(const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t in_stride_outer,
                            size_t in_stride_inner, u32 n_outer, u64 *out, u32 out_polys, u32 out_slot, hipStream_t st,
-                           bool fold = false);
+                           bool fold = false, bool skip_q = false);
 void launch_scale_pq_expand(const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t in_stride_outer,
                             size_t in_stride_inner, u32 n_outer, u64 *out, u32 out_polys, u32 out_slot, hipStream_t st,
                             bool fold = false);

@@ -147,13 +147,20 @@ bool launch_ntt_digits(const NttPlan &pl, const u64 *d2, u64 *dig, u32 nb, u32 L
                            (sigma && folded_layout) ? 1u : 0u);
 }
 
+bool ntt_supports_extra(const NttPlan &pl, bool folded)
+{
+    if (pl.force_generic || !pl.twp) return false;
+    if (folded) return pl.twc_fold != nullptr;
+    return pl.twc != nullptr && ntt_fast_s0(pl.logN) == 0;
+}
+
 void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, hipStream_t st, bool sigma,
-                bool folded)
+                bool folded, const NttExtra *ex)
 {
     if (!nlimbs) return;
     if (folded) {  // two half-size slices per limb, outer stage done by the neighbouring kernels
         (void)launch_ntt_fast(pl.twp, pl.twc_fold, pl.dc, pl.N, pl.logN, 1, data, nlimbs, mod_base, mod_count, inverse, sigma,
-                              pl.num_cus, st);
+                              pl.num_cus, st, nullptr, 0, 0, ex);
         return;
     }
     NttArgs a;
@@ -185,10 +192,10 @@ void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_
     if (!inverse) {
         for (u32 ms = 1; ms < (1u << a.s0); ms <<= 1)
             hipLaunchKernelGGL(ntt_global_stage<false>, ggrid, dim3(256), 0, st, a, ms, 0u);
-        if (!(fast_ok && launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, a.s0, data, nlimbs, mod_base, mod_count, false, sigma, pl.num_cus, st)))
+        if (!(fast_ok && launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, a.s0, data, nlimbs, mod_base, mod_count, false, sigma, pl.num_cus, st, nullptr, 0, 0, ex)))
             hipLaunchKernelGGL(ntt_lds_generic<false>, dim3(nlimbs << a.s0), dim3(threads), lds, st, a);
     } else {
-        if (!(fast_ok && launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, a.s0, data, nlimbs, mod_base, mod_count, true, sigma, pl.num_cus, st)))
+        if (!(fast_ok && launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, a.s0, data, nlimbs, mod_base, mod_count, true, sigma, pl.num_cus, st, nullptr, 0, 0, ex)))
             hipLaunchKernelGGL(ntt_lds_generic<true>, dim3(nlimbs << a.s0), dim3(threads), lds, st, a);
         for (u32 ms = (1u << a.s0) >> 1; ms >= 1; ms >>= 1)
             hipLaunchKernelGGL(ntt_global_stage<true>, ggrid, dim3(256), 0, st, a, ms, ms == 1 ? 1u : 0u);

@@ -49,6 +49,13 @@ struct NttFastArgs {
     u32 lift_L;
     u32 sigma_split;  // forward, lane order: store as if the limb were 2^sigma_split slices (the folded layout)
     u32 mod_base, mod_count;
+    // inverse, standard order in: also write the lane-ordered EVALUATION input of operand polynomials to the Q limbs of
+    // the QP operand array (the tensor product then needs no forward transform for them).  Limb li of the input
+    // [nb][copy_K][2][copy_L] is copied iff it belongs to operand 0 of its bin: -> copy_out[bin][4][copy_M][N], slot c.
+    u64 *copy_out;
+    u32 copy_K, copy_L, copy_M;
+    // forward: the transformed limbs are a compact enumeration of [nb][4][skip_M] without limbs < skip_L of slots 0, 1
+    u32 skip_L, skip_M;
 };
 
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
@@ -227,9 +234,19 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
 
     u32 item = blockIdx.x;
     if (item >= a.nitems) return;
+    // slice index in memory of work item `it` (forward: compact enumeration that skips the Q limbs of slots 0 and 1)
+    auto slice_of = [&](u32 it) -> size_t {
+        u32 lb = it >> a.s0;
+        if (!INV && a.skip_L) {
+            const u32 P = a.skip_M - a.skip_L, per = 2 * P + 2 * a.skip_M;
+            const u32 cb = lb / per, r = lb % per;
+            lb = cb * 4 * a.skip_M + (r < 2 * P ? (r / P) * a.skip_M + a.skip_L + r % P : 2 * a.skip_M + (r - 2 * P));
+        }
+        return ((size_t)lb << a.s0) + (it & ((1u << a.s0) - 1));
+    };
     // prefetch the first slice (A-layout addresses are also the coalesced copy-in/out order)
     {
-        const u64 *g = gdata + (size_t)item * n;
+        const u64 *g = gdata + slice_of(item) * n;
         const u32 st = (INV && SIGMA) ? 2 * T : NB;  // sigma order: pair k of thread tau at 2 (k T + tau)
         if (!INV && a.lift_L) g = a.lift_src + (size_t)(item / a.lift_L) * n;
 #pragma unroll
@@ -261,7 +278,8 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
         const u32 next = item + gridDim.x;
         // forward: the next slice's loads fly during the whole transform (pass A has scalar twiddles, so
         // the 64 extra VGPRs fit); inverse: they are issued before pass A' instead (see below)
-        const u32 limb = item >> a.s0, blk = item & ((1u << a.s0) - 1);
+        const size_t slice = slice_of(item);
+        const u32 limb = (u32)(slice >> a.s0), blk = item & ((1u << a.s0) - 1);
         const u32 mod = a.mod_base + limb % a.mod_count;
         const Mod m = gdc->mod[mod];
         const u64 q = m.q, q2 = 2 * m.q, q4 = 4 * m.q, nq = 0 - m.q;
@@ -284,7 +302,7 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
 #define TWC(sc, j) twc[T * ((32u >> C) * ((1u << (sc)) - 1) + (j))]
 #endif
 #endif
-        u64 *g = gdata + (size_t)item * n;
+        u64 *g = gdata + slice * n;
 
         STAMP(1);
         if (!INV) {
@@ -311,7 +329,7 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
 #else
                     if (next < a.nitems) {
 #endif
-                        const u64 *gn = a.lift_L ? a.lift_src + (size_t)(next / a.lift_L) * n : gdata + (size_t)next * n;
+                        const u64 *gn = a.lift_L ? a.lift_src + (size_t)(next / a.lift_L) * n : gdata + slice_of(next) * n;
 #pragma unroll
                         for (int k = 0; k < 16; k++) {
                             const u64x2 v = *reinterpret_cast<const u64x2 *>(gn + 2 * tau + NB * k);
@@ -432,6 +450,19 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
                     const u64x2 v = *reinterpret_cast<const u64x2 *>(&lds[phi(32 * tau + 2 * k)]);
                     x[2 * k] = v.x;
                     x[2 * k + 1] = v.y;
+                }
+                // the registers now hold this slice of the EVALUATION input in lane order: operand-0 polynomials keep a
+                // copy as the Q limbs of the QP operand array
+                if (a.copy_out && (limb / (2 * a.copy_L)) % a.copy_K == 0) {
+                    const u32 bin = limb / (2 * a.copy_L * a.copy_K), c = (limb / a.copy_L) & 1, i = limb % a.copy_L;
+                    u64 *co = a.copy_out + ((((size_t)bin * 4 + c) * a.copy_M + i) << a.s0) * n + (size_t)blk * n;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        u64x2 v;
+                        v.x = x[2 * k];
+                        v.y = x[2 * k + 1];
+                        *reinterpret_cast<u64x2 *>(co + 2 * (k * T + tau)) = v;
+                    }
                 }
             }
             // ---- pass C': distances 1, 2, .. 2^(C-1) -----------------------------------------------------------
@@ -579,7 +610,7 @@ void ntt_sigma_inverse_map(u32 logN, u32 s0, std::vector<u32> &map)
 
 bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
                      u32 mod_count, bool inverse, bool sigma, u32 num_cus, hipStream_t st, const u64 *lift_src, u32 lift_L,
-                     u32 sigma_split)
+                     u32 sigma_split, const NttExtra *ex)
 {
     const u32 logn = logN - s0;
     if (logn < 12 || logn > 14) return false;
@@ -598,6 +629,12 @@ bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N,
     a.sigma_split = (!inverse && s0 == 0) ? sigma_split : 0;
     a.mod_base = mod_base;
     a.mod_count = mod_count;
+    a.copy_out = (ex && inverse && !sigma) ? ex->copy_out : nullptr;
+    a.copy_K = ex ? ex->copy_K : 1;
+    a.copy_L = ex ? ex->copy_L : 1;
+    a.copy_M = ex ? ex->copy_M : 1;
+    a.skip_L = (ex && !inverse) ? ex->skip_L : 0;
+    a.skip_M = ex ? ex->skip_M : 0;
     // resident workgroups per CU by LDS: 136 KiB -> 1, 68 KiB -> 2, 34 KiB -> 4
     const u32 per_cu = logn == 14 ? 1 : (logn == 13 ? 2 : 4);
     const u32 maxg = num_cus * per_cu;

@@ -28,7 +28,7 @@ typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 template <int BPT>
 __global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
                                                       const u64 *__restrict__ idx, const u64 *__restrict__ minus,
-                                                      const u64 *__restrict__ db, u64 *__restrict__ acc)
+                                                      const u64 *__restrict__ db, u64 *__restrict__ acc, u32 bstride)
 {
     const u32 n = 2 * (blockIdx.x * TPB + threadIdx.x);
     const u32 l = blockIdx.y;
@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *__restric
     const Mod m = dc->mod[l];
     const size_t LN = (size_t)L * N;
     const u64 *pi = idx + ((size_t)h * E) * 2 * LN + (size_t)l * N + n;
-    const u64 *pd = db + (((size_t)h * b + beta0) * E) * LN + (size_t)l * N + n;
+    const u64 *pd = db + (((size_t)h * bstride + beta0) * E) * LN + (size_t)l * N + n;  // db is [K][bstride][E][L][N]
     const size_t bin_stride = (size_t)E * LN;
     U128 a[BPT][2][2];
 #pragma unroll
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *__restric
 template <int BPT, int CPT>
 __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
                                                           const u64 *__restrict__ idx, const u64 *__restrict__ minus,
-                                                          const u64 *__restrict__ db, u64 *__restrict__ acc)
+                                                          const u64 *__restrict__ db, u64 *__restrict__ acc, u32 bstride)
 {
     // CPT coefficients per thread: 2 -> 16-byte lanes; 1 -> 8-byte lanes, half the accumulator registers
     const u32 n = CPT * (blockIdx.x * TPB + threadIdx.x);
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
     const Mod m = dc->mod[l];
     const size_t LN = (size_t)L * N;
     const u64 *pi = idx + ((size_t)h * E) * 2 * LN + (size_t)l * N + n;
-    const u64 *pd = db + (((size_t)h * b + beta0) * E) * LN + (size_t)l * N + n;
+    const u64 *pd = db + (((size_t)h * bstride + beta0) * E) * LN + (size_t)l * N + n;  // db is [K][bstride][E][L][N]
     const size_t bin_stride = (size_t)E * LN;
     ColAcc a[BPT][2][CPT];
 #pragma unroll
@@ -162,8 +162,9 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
 }
 
 void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
-                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli)
+                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride)
 {
+    if (!bstride) bstride = b;
     // bin layers per thread: the largest divisor of b that keeps the accumulators in registers
     const bool mad = small_moduli && E <= COLACC_MAX_TOTAL;
     const int cap = mad ? 7 : 8;
@@ -179,12 +180,12 @@ void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, cons
     dim3 grid((N / cpt + TPB - 1) / TPB, L, K * (b / bpt));
 #define SA(B_)                                                                                                       \
     do {                                                                                                             \
-        if (mad && cpt == 1) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 1>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc); \
-        else if (mad) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 2>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc); \
-        else hipLaunchKernelGGL(stage_a_kernel<B_>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc);  \
+        if (mad && cpt == 1) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 1>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride); \
+        else if (mad) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 2>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride); \
+        else hipLaunchKernelGGL(stage_a_kernel<B_>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride);  \
     } while (0)
     switch (bpt) {
-        case 8: hipLaunchKernelGGL(stage_a_kernel<8>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc); break;
+        case 8: hipLaunchKernelGGL(stage_a_kernel<8>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride); break;
         case 7: SA(7); break;
         case 6: SA(6); break;
         case 5: SA(5); break;
@@ -305,7 +306,8 @@ __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 *x,
 
 template <bool SCALE, bool FOLD, u32 L, bool MAD>
 __global__ void __launch_bounds__(TPB) expand_kernel(const DevConsts *__restrict__ dc, u32 N, const u64 *__restrict__ in,
-                                                     size_t so, size_t si, u64 *__restrict__ out, u32 out_polys, u32 out_slot)
+                                                     size_t so, size_t si, u64 *__restrict__ out, u32 out_polys, u32 out_slot,
+                                                     u32 skip_q)
 {
     const u32 n = blockIdx.x * TPB + threadIdx.x;
     const u32 H = N / 2;
@@ -332,6 +334,7 @@ __global__ void __launch_bounds__(TPB) expand_kernel(const DevConsts *__restrict
     }
 #pragma unroll
     for (u32 a = 0; a < M; a++) {
+        if (!SCALE && a < L && skip_q) continue;  // the Q limbs already hold the operand's EVALUATION form (NttExtra)
         if (FOLD) {
             u64 y0, y1;
             fold_store(dc, a, y[0][a], y[NP - 1][a], y0, y1);
@@ -344,15 +347,16 @@ __global__ void __launch_bounds__(TPB) expand_kernel(const DevConsts *__restrict
 }
 
 static void launch_expand_common(bool scale, bool fold, const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t so, size_t si,
-                                 u32 n_outer, u64 *out, u32 out_polys, u32 out_slot, hipStream_t st)
+                                 u32 n_outer, u64 *out, u32 out_polys, u32 out_slot, hipStream_t st, bool skip_q = false)
 {
+    const u32 sq = skip_q ? 1u : 0u;
     dim3 grid(((fold ? N / 2 : N) + TPB - 1) / TPB, n_outer * 2);
 #define EX(S_, F_, L_)                                                                                                     \
     do {                                                                                                                   \
         if (g_small_moduli)                                                                                                \
-            hipLaunchKernelGGL((expand_kernel<S_, F_, L_, true>), grid, dim3(TPB), 0, st, dc, N, in, so, si, out, out_polys, out_slot); \
+            hipLaunchKernelGGL((expand_kernel<S_, F_, L_, true>), grid, dim3(TPB), 0, st, dc, N, in, so, si, out, out_polys, out_slot, sq); \
         else                                                                                                               \
-            hipLaunchKernelGGL((expand_kernel<S_, F_, L_, false>), grid, dim3(TPB), 0, st, dc, N, in, so, si, out, out_polys, out_slot); \
+            hipLaunchKernelGGL((expand_kernel<S_, F_, L_, false>), grid, dim3(TPB), 0, st, dc, N, in, so, si, out, out_polys, out_slot, sq); \
     } while (0)
 #define EXL(L_)                                                   \
     case L_:                                                      \
@@ -367,9 +371,9 @@ static void launch_expand_common(bool scale, bool fold, const DevConsts *dc, u32
 #undef EX
 }
 void launch_expand_q_to_qp(const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t so, size_t si, u32 n_outer, u64 *out,
-                           u32 out_polys, u32 out_slot, hipStream_t st, bool fold)
+                           u32 out_polys, u32 out_slot, hipStream_t st, bool fold, bool skip_q)
 {
-    launch_expand_common(false, fold, dc, N, L, in, so, si, n_outer, out, out_polys, out_slot, st);
+    launch_expand_common(false, fold, dc, N, L, in, so, si, n_outer, out, out_polys, out_slot, st, skip_q);
 }
 void launch_scale_pq_expand(const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t so, size_t si, u32 n_outer, u64 *out,
                             u32 out_polys, u32 out_slot, hipStream_t st, bool fold)

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <random>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -30,9 +31,20 @@ static int fail(int code, const std::string &msg)
         if (e_ != hipSuccess)                                                                          \
             return fail(PIEHIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
     } while (0)
-#define NEED(h)                                                 \
+struct piehip_ctx;
+static void join_pending(piehip_ctx *h);
+static void mark_dirty(piehip_ctx *h);
+// every entry point except piehip_run first orders the handle's stream behind the bin-layer queues of earlier runs
+#define NEED_RO(h)                                              \
     do {                                                        \
         if (!(h)) return fail(PIEHIP_EINVAL, "null handle");    \
+        join_pending(h);                                        \
+    } while (0)
+// ... and, unless it only reads (NEED_RO), may queue work on the handle's stream that the next run has to wait for
+#define NEED(h)                                                 \
+    do {                                                        \
+        NEED_RO(h);                                             \
+        mark_dirty(h);                                          \
     } while (0)
 
 namespace {
@@ -60,6 +72,13 @@ struct piehip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    std::vector<hipStream_t> side_streams;        // extra queues of run(): one group of bin layers each (see piehip_run)
+    std::vector<hipEvent_t> ev_join;
+    hipEvent_t ev_fork = nullptr;
+    u32 run_streams = 0;                          // piehip_set_run_streams: 0 = all queues
+    bool inputs_dirty = true;                     // inputs / keys / database changed on the handle's stream since the last run()
+    hipEvent_t wait_before_results = nullptr;     // set while run() enqueues a group: its result-writing kernel waits for this
+    bool pending_join = false;                    // run() left work on the bin-layer queues that the handle's stream has not waited for
     DevConsts *d_dc = nullptr;
     u64 *d_tables = nullptr;  // [(M+1)][4][N]
     u64 *d_twp = nullptr;     // [(M+1)][2][N][2] interleaved {w, w_shoup}
@@ -104,6 +123,15 @@ struct piehip_ctx {
 
     size_t LN() const { return (size_t)hp.L * hp.N; }
 };
+
+static void join_pending(piehip_ctx *h)
+{
+    if (!h->pending_join) return;
+    for (size_t g = 0; g < h->ev_join.size(); g++) (void)hipStreamWaitEvent(h->stream, h->ev_join[g], 0);
+    h->pending_join = false;
+}
+
+static void mark_dirty(piehip_ctx *h) { h->inputs_dirty = true; }
 
 static const char *KNAMES[PIEHIP_NKERNELS] = {"stage_a_mac", "ntt_fwd", "ntt_inv",  "expand",   "tensor",    "scale_round",
                                               "digits",      "relin",   "mask_mul", "encode",   "automorph", "other"};
@@ -202,17 +230,26 @@ static void ws_free(MulWs &w)
 // ---- schedule pieces ----------------------------------------------------------------------------
 // sigma: lane order on the EVALUATION side; fold: outer stage applied by the neighbouring kernels (both only
 // take effect when the context supports them; callers pass the same flags to those neighbours)
-static void ntt(piehip_ctx *h, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inv, bool sigma = false, bool fold = false)
+static void ntt(piehip_ctx *h, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inv, bool sigma = false, bool fold = false,
+                const NttExtra *ex = nullptr)
 {
     ProfScope ps(h, inv ? PIEHIP_K_NTT_INV : PIEHIP_K_NTT_FWD, 16.0 * h->hp.N * nlimbs);
-    launch_ntt(h->plan, data, nlimbs, mod_base, mod_count, inv, h->stream, sigma && h->sigma_on, fold && h->fold_on);
+    launch_ntt(h->plan, data, nlimbs, mod_base, mod_count, inv, h->stream, sigma && h->sigma_on, fold && h->fold_on, ex);
+}
+// The X operand of a ciphertext multiplication is available in EVALUATION format before its inverse transform; when
+// the register-blocked kernel runs that transform it also drops a lane-ordered copy into the Q limbs of the QP operand
+// array, and the forward transform over QP skips those limbs (8 of 36 per bin layer at L = 4).
+static bool xq_reuse(const piehip_ctx *h)
+{
+    static const bool off = [] { const char *e = getenv("PIEHIP_XQ"); return e && e[0] == '0'; }();  // experiments
+    return !off && h->sigma_on && ntt_supports_extra(h->plan, h->fold_on);
 }
 
 // BV key switch of the COEFFICIENT-format polynomials at w.d2c with `key`, added to the EVALUATION
 // ciphertexts at w.d01, optionally multiplied by mask plaintexts: out[nb][2][L][N]
 // sigma: w.d01 and the digits are in lane order, key/mask are lane-ordered copies, out is written in standard order
 static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, const u64 *mask, u64 *out, bool sigma = false,
-                              bool fold = false, size_t key_stride = 0, u32 key_group = 1)
+                              bool fold = false, size_t key_stride = 0, u32 key_group = 1, bool out_is_result = false)
 {
     const u32 N = h->hp.N, L = h->hp.L;
     const size_t LN = h->LN();
@@ -231,6 +268,8 @@ static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, c
         ntt(h, w.dig, nb * L * L, 0, L, false, sigma, fold);
     }
     {
+        // the result buffer may still be read by work the caller queued on the handle's stream before this run
+        if (h->wait_before_results && out_is_result) (void)hipStreamWaitEvent(h->stream, h->wait_before_results, 0);
         ProfScope ps(h, PIEHIP_K_RELIN, W * (nb * ((double)L * L + 2 * L + 2 * L + (mask ? L : 0)) + 2.0 * L * L));
         launch_relin_mac(h->d_dc, N, L, w.d01, 2 * LN, w.dig, key, mask, out, nb, h->stream,
                          (sigma && h->sigma_on) ? h->d_sigma_inv : nullptr, key_stride, key_group);
@@ -242,7 +281,7 @@ static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, c
 // X polynomial (o,c) at x + o*sx + c*LN, Y likewise.  relin: out[nb][2][L][N] (times mask if given);
 // otherwise out[nb][3][L][N] holds the EVALUATION-format tensor result.
 static void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const u64 *y, size_t sy, u32 nb, bool relin,
-                        const u64 *mask, u64 *out)
+                        const u64 *mask, u64 *out, bool xq_ready = false, bool out_is_result = false)
 {
     const u32 N = h->hp.N, L = h->hp.L, M = h->hp.M;
     const size_t LN = h->LN();
@@ -250,11 +289,18 @@ static void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const 
     set_small_moduli(h->small_moduli);
     {
         ProfScope ps(h, PIEHIP_K_EXPAND, W * nb * (4.0 * L + 4.0 * M));
-        launch_expand_q_to_qp(h->d_dc, N, L, x, sx, LN, nb, w.eqp, 4, 0, h->stream, h->fold_on);
+        launch_expand_q_to_qp(h->d_dc, N, L, x, sx, LN, nb, w.eqp, 4, 0, h->stream, h->fold_on, xq_ready);
         launch_scale_pq_expand(h->d_dc, N, L, y, sy, LN, nb, w.eqp, 4, 2, h->stream, h->fold_on);
     }
     // the QP operands and the tensor result never leave the library: lane order, no LDS transposes
-    ntt(h, w.eqp, nb * 4 * M, 0, M, false, true, true);
+    if (xq_ready) {
+        NttExtra ex;
+        ex.skip_L = L;
+        ex.skip_M = M;
+        ntt(h, w.eqp, nb * (4 * M - 2 * L), 0, M, false, true, true, &ex);
+    } else {
+        ntt(h, w.eqp, nb * 4 * M, 0, M, false, true, true);
+    }
     {
         ProfScope ps(h, PIEHIP_K_TENSOR, W * nb * 7.0 * M);
         launch_tensor(h->d_dc, N, M, w.eqp, w.dqp, nb, h->stream);
@@ -266,7 +312,7 @@ static void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const 
             launch_scale_round(h->d_dc, N, L, w.dqp, nb, w.d01, 2 * LN, w.d2c, LN, h->stream, h->fold_on, false);
         }
         ntt(h, w.d01, nb * 2 * L, 0, L, false, true, true);
-        enqueue_keyswitch(h, w, nb, h->sigma_on ? h->d_evk_sigma : h->d_evk, mask, out, true, true);
+        enqueue_keyswitch(h, w, nb, h->sigma_on ? h->d_evk_sigma : h->d_evk, mask, out, true, true, 0, 1, out_is_result);
     } else {
         {
             ProfScope ps(h, PIEHIP_K_SCALE, W * nb * (3.0 * M + 3.0 * L));
@@ -327,6 +373,21 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
     } else {
         CHK_(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->own_stream = true;
+    }
+    {
+        const char *es = getenv("PIEHIP_STREAMS");  // experiments: PIEHIP_STREAMS=n, 1 keeps run() on one stream
+        int ns = es ? atoi(es) : 2;
+        if (ns < 1) ns = 1;
+        if (ns > 16) ns = 16;
+        if (ns > 1) CHK_(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < ns && ns > 1; i++) {
+            hipStream_t s = nullptr;
+            hipEvent_t e = nullptr;
+            CHK_(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            h->side_streams.push_back(s);
+            CHK_(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->ev_join.push_back(e);
+        }
     }
     const u32 M = h->hp.M;
     CHK_(hipMalloc((void **)&h->d_dc, sizeof(DevConsts)));
@@ -448,6 +509,12 @@ int piehip_destroy(piehip_handle h)
     dev_free(&h->fp_out);
     dev_free(&h->fp_negkeys);
     if (h->fp_negmaps) (void)hipFree(h->fp_negmaps);
+    for (hipStream_t s : h->side_streams) {
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamDestroy(s);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (hipEvent_t e : h->ev_join) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PIEHIP_OK;
@@ -455,20 +522,20 @@ int piehip_destroy(piehip_handle h)
 
 int piehip_get_moduli(piehip_handle h, uint64_t *out)
 {
-    NEED(h);
+    NEED_RO(h);
     memcpy(out, h->hp.moduli.data(), sizeof(u64) * (h->hp.M + 1));
     return PIEHIP_OK;
 }
 int piehip_get_root(piehip_handle h, uint32_t mi, uint64_t *psi)
 {
-    NEED(h);
+    NEED_RO(h);
     if (mi > h->hp.M) return fail(PIEHIP_EINVAL, "mod_index out of range");
     *psi = h->hp.psi[mi];
     return PIEHIP_OK;
 }
 int piehip_get_twiddles(piehip_handle h, uint32_t mi, uint64_t *fwd, uint64_t *inv)
 {
-    NEED(h);
+    NEED_RO(h);
     if (mi > h->hp.M) return fail(PIEHIP_EINVAL, "mod_index out of range");
     if (fwd) memcpy(fwd, h->hp.tw[mi].data(), sizeof(u64) * h->hp.N);
     if (inv) memcpy(inv, h->hp.itw[mi].data(), sizeof(u64) * h->hp.N);
@@ -476,7 +543,7 @@ int piehip_get_twiddles(piehip_handle h, uint32_t mi, uint64_t *fwd, uint64_t *i
 }
 int piehip_get_slot_positions(piehip_handle h, uint32_t *pos)
 {
-    NEED(h);
+    NEED_RO(h);
     memcpy(pos, h->hp.slot_pos.data(), sizeof(u32) * h->hp.N);
     return PIEHIP_OK;
 }
@@ -774,45 +841,128 @@ int piehip_set_minus_device(piehip_handle h, const void *d_minus)
     return PIEHIP_OK;
 }
 
-int piehip_run(piehip_handle h)
+// Bin layers [b0, b0 + nb) of run() on the handle's current stream: stage A, then the product chain.
+static void enqueue_run_bins(piehip_ctx *h, u32 b0, u32 nb, u64 *results)
 {
-    NEED(h);
-    if (!h->K || !h->d_db) return fail(PIEHIP_ESTATE, "run: database not loaded");
-    if (!h->d_evk) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
-    if (!h->d_idx || !h->d_minus) return fail(PIEHIP_ESTATE, "run: setIndex / setMinusCompareElement not called");
-    HIPCHK(hipSetDevice(h->device));
-    const u32 N = h->hp.N, L = h->hp.L, K = h->K, b = h->b, E = h->E;
+    const u32 N = h->hp.N, L = h->hp.L, M = h->hp.M, K = h->K, b = h->b, E = h->E;
     const size_t LN = h->LN();
     const double W = 8.0 * N;
-    h->recs.clear();
-    h->pool_used = 0;
-    {   // stage A: all inner products of all bin layers in one launch (BatchedFHEHIPPIE.cpp:101-116)
-        ProfScope ps(h, PIEHIP_K_STAGE_A, W * ((double)b * K * E * L + (double)K * E * 2 * L + 2.0 * L + (double)b * K * 2 * L));
-        launch_stage_a(h->d_dc, N, L, K, b, E, h->d_idx, h->d_minus, h->d_db, h->d_acc, h->stream, h->small_moduli);
+    MulWs w = h->ws;  // view of the workspace rows of these bin layers
+    w.nb = nb;
+    w.eqp += (size_t)b0 * 4 * M * N;
+    w.dqp += (size_t)b0 * 3 * M * N;
+    w.d01 += (size_t)b0 * 2 * LN;
+    w.d2c += (size_t)b0 * LN;
+    w.dig += (size_t)b0 * L * LN;
+    u64 *acc = h->d_acc + (size_t)b0 * K * 2 * LN;
+    u64 *prod = h->d_prod ? h->d_prod + (size_t)b0 * 2 * LN : nullptr;
+    u64 *out = results + (size_t)b0 * 2 * LN;
+    const u64 *masks = (h->sigma_on ? h->d_masks_sigma : h->d_masks) + (size_t)b0 * LN;
+    {   // stage A: all inner products of these bin layers in one launch (BatchedFHEHIPPIE.cpp:101-116)
+        ProfScope ps(h, PIEHIP_K_STAGE_A, W * ((double)nb * K * E * L + (double)K * E * 2 * L + 2.0 * L + (double)nb * K * 2 * L));
+        launch_stage_a(h->d_dc, N, L, K, nb, E, h->d_idx, h->d_minus, h->d_db + (size_t)b0 * E * LN, acc, h->stream, h->small_moduli, b);
     }
     // every accumulator enters a ct x ct product exactly once: switch them all to COEFFICIENT format
-    ntt(h, h->d_acc, b * K * 2 * L, 0, L, true, false, true);
+    const bool xq = xq_reuse(h) && K > 1;
+    NttExtra ex;
+    ex.copy_out = w.eqp;
+    ex.copy_K = K;
+    ex.copy_L = L;
+    ex.copy_M = M;
+    ntt(h, acc, nb * K * 2 * L, 0, L, true, false, true, xq ? &ex : nullptr);
     // product chain over the inner hash functions (BatchedFHEHIPPIE.cpp:117-124); the mask multiply
     // (:126) is fused into the last key switch
-    const u64 *x = h->d_acc;
+    const u64 *x = acc;
     size_t sx = (size_t)K * 2 * LN;
     for (u32 hf = 1; hf < K; hf++) {
         const bool last = hf + 1 == K;
-        u64 *dst = last ? h->d_out : h->d_prod;
-        enqueue_mul(h, h->ws, x, sx, h->d_acc + (size_t)hf * 2 * LN, (size_t)K * 2 * LN, b, true, last ? (h->sigma_on ? h->d_masks_sigma : h->d_masks) : nullptr, dst);
+        u64 *dst = last ? out : prod;
+        enqueue_mul(h, w, x, sx, acc + (size_t)hf * 2 * LN, (size_t)K * 2 * LN, nb, true, last ? masks : nullptr, dst, xq, last);
         if (!last) {
-            ntt(h, h->d_prod, b * 2 * L, 0, L, true, false, true);
-            x = h->d_prod;
+            ex.copy_K = 1;  // the product is the X operand of the next multiplication
+            ntt(h, prod, nb * 2 * L, 0, L, true, false, true, xq ? &ex : nullptr);
+            x = prod;
             sx = 2 * LN;
         }
+    }
+}
+
+int piehip_run_into(piehip_handle h, void *d_results)
+{
+    if (!h) return fail(PIEHIP_EINVAL, "null handle");
+    if (!d_results) return fail(PIEHIP_EINVAL, "null result buffer");
+    if (!h->K || !h->d_db) return fail(PIEHIP_ESTATE, "run: database not loaded");
+    if (!h->d_evk) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
+    if (!h->d_idx || !h->d_minus) return fail(PIEHIP_ESTATE, "run: setIndex / setMinusCompareElement not called");
+    if (h->K < 2) return fail(PIEHIP_EINVAL, "run: at least two inner hash functions");
+    HIPCHK(hipSetDevice(h->device));
+    const u32 b = h->b;
+    h->recs.clear();
+    h->pool_used = 0;
+    // Bin layers are independent: groups of them go to separate queues.  Most launches of one group leave part of the
+    // chip idle (a transform launch is 0.4 .. 2 rounds of workgroups); another group's kernels fill it.
+    // Ordering against the handle's stream:
+    //   * inputs changed since the last run (setIndex, keys, database): the queues wait for the handle's stream first;
+    //   * always: the kernel that writes the results waits for everything the caller queued on the handle's stream
+    //     before this call (it may still be reading the result buffer of an earlier run);
+    //   * the handle's stream joins the queues lazily, in the next entry point that is not a run (NEED / piehip_join),
+    //     so back-to-back runs of one query batch keep every queue busy across run boundaries.
+    const size_t nq = h->side_streams.size();
+    const u32 ng = (u32)std::min<size_t>(h->run_streams ? h->run_streams : nq, std::min<size_t>(nq, b));
+    if (ng > 1) {
+        struct Restore {
+            piehip_ctx *h;
+            hipStream_t s;
+            ~Restore()
+            {
+                h->stream = s;
+                h->wait_before_results = nullptr;
+            }
+        } restore{h, h->stream};
+        HIPCHK(hipEventRecord(h->ev_fork, restore.s));
+        u32 b0 = 0;
+        for (u32 g = 0; g < ng; g++) {
+            const u32 nb = b / ng + (g < b % ng ? 1 : 0);
+            if (h->inputs_dirty) HIPCHK(hipStreamWaitEvent(h->side_streams[g], h->ev_fork, 0));
+            h->stream = h->side_streams[g];
+            h->wait_before_results = h->inputs_dirty ? nullptr : h->ev_fork;
+            enqueue_run_bins(h, b0, nb, (u64 *)d_results);
+            HIPCHK(hipEventRecord(h->ev_join[g], h->side_streams[g]));
+            b0 += nb;
+        }
+        h->pending_join = true;
+        h->inputs_dirty = false;
+    } else {
+        join_pending(h);
+        enqueue_run_bins(h, 0, b, (u64 *)d_results);
     }
     HIPCHK(hipGetLastError());
     return PIEHIP_OK;
 }
 
+int piehip_run(piehip_handle h)
+{
+    if (!h) return fail(PIEHIP_EINVAL, "null handle");
+    if (!h->d_out) return fail(PIEHIP_ESTATE, "run: database not loaded");
+    return piehip_run_into(h, h->d_out);
+}
+
+int piehip_join(piehip_handle h)
+{
+    NEED_RO(h);
+    return PIEHIP_OK;
+}
+
+int piehip_set_run_streams(piehip_handle h, uint32_t n)
+{
+    NEED_RO(h);
+    h->run_streams = n;
+    return PIEHIP_OK;
+}
+
 int piehip_sync(piehip_handle h)
 {
-    NEED(h);
+    NEED_RO(h);
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     return PIEHIP_OK;
@@ -830,7 +980,7 @@ int piehip_get_results(piehip_handle h, uint64_t *out)
 }
 int piehip_results_device(piehip_handle h, void **d_out)
 {
-    NEED(h);
+    NEED_RO(h);
     if (!h->d_out) return fail(PIEHIP_ESTATE, "no results");
     *d_out = h->d_out;
     return PIEHIP_OK;
@@ -911,8 +1061,14 @@ int piehip_eval_mult(piehip_handle h, const uint64_t *x, const uint64_t *y, uint
         ws_free(w);
         return rc;
     }
-    ntt(h, dxy, nct * 4 * L, 0, L, true, false, true);
-    enqueue_mul(h, w, dxy, 4 * LN, dxy + 2 * LN, 4 * LN, nct, relin != 0, nullptr, dout);
+    const bool xq = xq_reuse(h);
+    NttExtra ex;  // operand layout [nct][x, y][2][L]: x is "operand 0" of every pair
+    ex.copy_out = w.eqp;
+    ex.copy_K = 2;
+    ex.copy_L = L;
+    ex.copy_M = h->hp.M;
+    ntt(h, dxy, nct * 4 * L, 0, L, true, false, true, xq ? &ex : nullptr);
+    enqueue_mul(h, w, dxy, 4 * LN, dxy + 2 * LN, 4 * LN, nct, relin != 0, nullptr, dout, xq);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     ws_free(w);
@@ -1404,7 +1560,7 @@ int piehip_client_relin_keygen(piehip_handle h, const uint64_t *sk, uint64_t see
 
 int piehip_rotation_galois(piehip_handle h, int32_t index, uint32_t *g)
 {
-    NEED(h);
+    NEED_RO(h);
     if (!g) return fail(PIEHIP_EINVAL, "null out");
     const u32 N = h->hp.N;
     const u64 m2 = 2ULL * N;
@@ -1498,7 +1654,7 @@ int piehip_client_decrypt(piehip_handle h, const uint64_t *sk, const uint64_t *c
 
 int piehip_set_profiling(piehip_handle h, int on)
 {
-    NEED(h);
+    NEED_RO(h);
     h->profiling = on != 0;
     h->recs.clear();
     h->pool_used = 0;
@@ -1507,7 +1663,7 @@ int piehip_set_profiling(piehip_handle h, int on)
 
 int piehip_profile_read(piehip_handle h, uint32_t *launches, double *ms, double *alg_bytes)
 {
-    NEED(h);
+    NEED_RO(h);
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     for (int k = 0; k < PIEHIP_NKERNELS; k++) {

@@ -175,6 +175,10 @@ class PieContext:
         _check(lib().piehip_bench_ntt(self._h, nlimbs, mod_count or self.M, int(inverse), iters, C.byref(ms)))
         return ms.value
 
+    def set_run_streams(self, n):
+        """run() spreads the bin layers over up to n HIP streams (0 = default, 1 = serial on the handle's stream)"""
+        _check(lib().piehip_set_run_streams(self._h, int(n)))
+
     def set_profiling(self, on):
         _check(lib().piehip_set_profiling(self._h, int(on)))
 
@@ -264,10 +268,18 @@ class BatchedFHEHIPPIE:
     def setMinusCompareElementDevice(self, ptr):
         _check(lib().piehip_set_minus_device(self.cc._h, ptr))
 
-    def run(self, sync=True):
-        _check(lib().piehip_run(self.cc._h))
+    def run(self, sync=True, into=None):
+        """into: device address of a caller-owned result buffer [b][2][L][N] (piehip_run_into)"""
+        if into is None:
+            _check(lib().piehip_run(self.cc._h))
+        else:
+            _check(lib().piehip_run_into(self.cc._h, into))
         if sync:
             _check(lib().piehip_sync(self.cc._h))
+
+    def join(self):
+        """order the context's stream behind the runs queued so far (no host wait)"""
+        _check(lib().piehip_join(self.cc._h))
 
     def sync(self):
         _check(lib().piehip_sync(self.cc._h))
