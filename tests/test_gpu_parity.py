@@ -441,3 +441,47 @@ def test_fhepie_error_behaviour(ob, pie):
     with pytest.raises(ValueError):
         op.setIndex(np.zeros((3, 2, 2, 1024), dtype=np.uint64))
     cc.close()
+
+
+# ---- stream order of run() (bin layers on the handle's own queues, lazy joins) -------------------------------
+@pytest.mark.parametrize("streams", [0, 1, 3])
+def test_run_pipelining_and_result_buffers(ob, pie, streams):
+    """back-to-back run() calls without a host wait, a change of inputs between runs, and piehip_run_into a caller-owned
+    buffer all give the oracle's ciphertexts, whatever the number of queues"""
+    import torch
+    N, L, t, nS, nC, k, e, K, E, b = 8192, 3, T32, 1500, 40, 3, 30, 2, 8, 7
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    cc.set_run_streams(streams)
+    rng = np.random.default_rng(99)
+    sk = o.keygen(11)
+    evk = o.relin_keygen(sk, 12)
+    d = _query(ob, o, rng, nS, nC, k, e, K, E, b)
+    db = np.stack([o.encode_eval(d["slots"][h, bn, j]) for h in range(K) for bn in range(b) for j in range(E)]).reshape(K, b, E, L, N)
+    masks = np.stack([o.encode_eval(d["mask_slots"][bn]) for bn in range(b)])
+    idx = np.stack([o.encrypt_slots(sk, d["index"][h, j], 100 + h * E + j) for h in range(K) for j in range(E)]).reshape(K, E, 2, L, N)
+    minus = o.encrypt_slots(sk, d["minus"], 99)
+    idx2 = np.ascontiguousarray(idx[:, ::-1])          # a different query: index rows permuted
+    cc.load_relin_key(evk)
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    op.setMinusCompareElement(minus)
+    op.setIndex(idx)
+    want = o.pie_run(idx, minus, db, masks, evk)
+    want2 = o.pie_run(idx2, minus, db, masks, evk)
+    for _ in range(5):
+        op.run(sync=False)                              # pipelined
+    assert (op.getResultList() == want).all()
+    op.run(sync=False)
+    op.setIndex(idx2)                                   # joins, uploads on the handle's stream, marks the inputs dirty
+    op.run(sync=False)
+    op.run(sync=False)
+    assert (op.getResultList() == want2).all()
+    # caller-owned result buffers, alternating, read back through the handle's stream order (join + torch copy)
+    bufs = [torch.zeros((b, 2, L, N), dtype=torch.int64, device="cuda") for _ in range(2)]
+    op.setIndex(idx)
+    for i in range(4):
+        op.run(sync=False, into=bufs[i & 1].data_ptr())
+    op.sync()
+    for bf in bufs:
+        assert (bf.cpu().numpy().view(np.uint64) == want).all()
+    cc.close()
