@@ -226,7 +226,8 @@ __device__ __forceinline__ u64 crt_out(const u64 *y, const u64 *hat, u32 hat_str
 {
     U128 acc = dot128<NS, MAD>(y, hat, hat_stride);
     mac128(acc, v, tm.q - prodmod);  // - v * prodmod (mod tm); v <= ns: one Barrett reduction for the whole sum
-    return reduce128(acc, tm);
+    // MAD implies 2^59 < q < 2^60 for every modulus: up to 7 products plus the small terms stay below 2^123
+    return (MAD && NS <= 7) ? reduce123(acc, tm) : reduce128(acc, tm);
 }
 
 // Outer-stage folding.  For N >= 2^14 the transforms next to these kernels run as two half-size slices per limb
@@ -294,7 +295,7 @@ __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 *x,
         const Mod &pj = dc->mod[L + j];
         U128 acc = dot128<L, MAD>(y, &dc->PI_modp[0][j], 8);
         add128(acc, itot);
-        const u64 r = reduce128(acc, pj);
+        const u64 r = MAD ? reduce123(acc, pj) : reduce128(acc, pj);  // L <= 7 products + a 64-bit term
         out[L + j] = r;
         yp[j] = mul_shoup(r, dc->phat_inv[j], dc->phat_inv_sh[j], pj.q);
         fs2 += fixfrac(yp[j], pj);
@@ -434,7 +435,7 @@ __device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 
         U128 acc = dot128<Lp, MAD>(yp, &dc->tQF_modq[0][k], 8);
         mac128(acc, d[k], dc->tPinv_modq[k]);
         add128(acc, itot);
-        out[k] = reduce128(acc, qk);
+        out[k] = (MAD && L <= 5) ? reduce123(acc, qk) : reduce128(acc, qk);  // L + 2 products
     }
 }
 
@@ -589,8 +590,8 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restr
     for (int c = 0; c < 2; c++) {
         const u64x2 s = *reinterpret_cast<const u64x2 *>(d01 + (size_t)bin * stride01 + (size_t)c * LN + (size_t)j * N + n);
         u64x2 r;
-        r.x = addmod(reduce128(acc[c][0], m), s.x, m.q);
-        r.y = addmod(reduce128(acc[c][1], m), s.y, m.q);
+        r.x = addmod(MAD ? reduce123(acc[c][0], m) : reduce128(acc[c][0], m), s.x, m.q);  // L <= 7 products
+        r.y = addmod(MAD ? reduce123(acc[c][1], m) : reduce128(acc[c][1], m), s.y, m.q);
         if (mask) {
             r.x = mulmod(r.x, mk.x, m);
             r.y = mulmod(r.y, mk.y, m);

@@ -76,6 +76,19 @@ PH_HD u64 barrett128(u64 z1, u64 z0, const Mod &m)
     return r;
 }
 PH_HD u64 reduce128(U128 z, const Mod &m) { return barrett128(z.hi, z.lo, m); }
+// z < 2^123 and 2^59 < q < 2^60: one-word Barrett.  mu = floor(2^123 / q) = (r1:r0) >> 5 fits 64 bits; the quotient
+// estimate floor(floor(z / 2^59) mu / 2^64) is at most 3 below floor(z / q), so the remainder z - qhat q lies in
+// [0, 4q) < 2^62 and two conditional subtractions finish.  A third of the multiplications of barrett128.
+PH_HD u64 reduce123(U128 z, const Mod &m)
+{
+    const u64 mu = (m.r1 << 59) | (m.r0 >> 5);
+    const u64 zh = (z.hi << 5) | (z.lo >> 59);
+    const u64 qhat = mulhi(zh, mu);
+    u64 r = z.lo - qhat * m.q;
+    r = r >= 2 * m.q ? r - 2 * m.q : r;
+    r = r >= m.q ? r - m.q : r;
+    return r;
+}
 PH_HD u64 mulmod(u64 a, u64 b, const Mod &m)
 {
     U128 z = mul128(a, b);

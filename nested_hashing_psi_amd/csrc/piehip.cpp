@@ -87,7 +87,7 @@ struct piehip_ctx {
     bool fold_on = false;     // outermost NTT stage folded into the coefficient-wise kernels (N >= 2^14)
     u32 *d_inv_pos = nullptr; // EVALUATION position -> slot
     u32 *d_sigma_inv = nullptr;  // lane-order position -> standard position (identity for small rings)
-    bool small_moduli = false;   // all Q and P moduli < 2^60
+    bool small_moduli = false;   // all Q and P moduli in (2^59, 2^60): v_mad_u64_u32 column accumulators, one-word Barrett
     bool sigma_on = false;       // the register-blocked NTT (and hence the lane order) applies to this context
     u64 *d_evk_sigma = nullptr, *d_masks_sigma = nullptr;  // lane-ordered copies of key and masks
     u64 *d_hash_tbl = nullptr;   // [k][e][K][b][E] of the last piehip_build_db
@@ -458,7 +458,7 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
         h->sigma_on = h->d_twc != nullptr;
         h->small_moduli = true;
         for (u32 a = 0; a < M; a++)
-            if (h->hp.moduli[a] >> 60) h->small_moduli = false;
+            if ((h->hp.moduli[a] >> 59) != 1) h->small_moduli = false;  // the mad paths assume 2^59 < q < 2^60
     }
     h->plan.twp = h->d_twp;
     h->plan.twc = h->d_twc;
