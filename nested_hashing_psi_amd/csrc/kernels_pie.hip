@@ -252,7 +252,9 @@ __device__ __forceinline__ void fold_store(const DevConsts *dc, u32 a, u64 u, u6
 // The RNS width L is a template parameter: with run-time trip counts hipcc indexes the per-coefficient residue
 // arrays dynamically and spills them to scratch.
 // x[L] (mod Q) -> out[M]: Q limbs copied, P limbs = centred CRT lift
-template <u32 L, bool MAD>
+// YIN: x[] already holds the CRT digits y_i = [x_i (Q/q_i)^-1]_{q_i} (folded load with the merged constants); the Q
+// limbs of the output are then not produced
+template <u32 L, bool MAD, bool YIN = false>
 __device__ __forceinline__ void expand_core(const DevConsts *dc, const u64 *x, u64 *out)
 {
     constexpr u32 Lp = L + 1;
@@ -261,7 +263,7 @@ __device__ __forceinline__ void expand_core(const DevConsts *dc, const u64 *x, u
 #pragma unroll
     for (u32 i = 0; i < L; i++) {
         out[i] = x[i];
-        y[i] = mul_shoup(x[i], dc->qhat_inv[i], dc->qhat_inv_sh[i], dc->mod[i].q);
+        y[i] = YIN ? x[i] : mul_shoup(x[i], dc->qhat_inv[i], dc->qhat_inv_sh[i], dc->mod[i].q);
         fsum += fixfrac(y[i], dc->mod[i]);
     }
     const u64 v = (fsum + FIX_HALF) >> 60;
@@ -270,7 +272,7 @@ __device__ __forceinline__ void expand_core(const DevConsts *dc, const u64 *x, u
 }
 
 // x[L] (mod Q) -> out[M]: P limbs = round(P x / Q), Q limbs = centred CRT lift of that
-template <u32 L, bool MAD>
+template <u32 L, bool MAD, bool YIN = false>
 __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 *x, u64 *out)
 {
     constexpr u32 Lp = L + 1;
@@ -280,7 +282,7 @@ __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 *x,
 #pragma unroll
     for (u32 i = 0; i < L; i++) {
         const Mod &mi = dc->mod[i];
-        y[i] = mul_shoup(x[i], dc->qhat_inv[i], dc->qhat_inv_sh[i], mi.q);
+        y[i] = YIN ? x[i] : mul_shoup(x[i], dc->qhat_inv[i], dc->qhat_inv_sh[i], mi.q);
         // y_i P / q_i = y_i floor(P/q_i) + floor(y_i w_i / q_i) + (y_i w_i mod q_i) / q_i
         u64 fl, z;
         divmod_shoup(y[i], dc->P_modq[i], dc->P_modq_sh[i], mi.q, fl, z);
@@ -305,11 +307,13 @@ __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 *x,
     for (u32 i = 0; i < L; i++) out[i] = crt_out<Lp, MAD>(yp, &dc->phat_modq[0][i], 8, v, dc->P_modq[i], dc->mod[i]);
 }
 
-template <bool SCALE, bool FOLD, u32 L, bool MAD>
+// SKIPQ (centred lift only): leave the Q limbs of the output alone, they already hold the operand's EVALUATION form
+template <bool SCALE, bool FOLD, u32 L, bool MAD, bool SKIPQ>
 __global__ void __launch_bounds__(TPB) expand_kernel(const DevConsts *__restrict__ dc, u32 N, const u64 *__restrict__ in,
-                                                     size_t so, size_t si, u64 *__restrict__ out, u32 out_polys, u32 out_slot,
-                                                     u32 skip_q)
+                                                     size_t so, size_t si, u64 *__restrict__ out, u32 out_polys, u32 out_slot)
 {
+    // the residues x_i themselves are not needed: the folded load multiplies by N^-1 (Q/q_i)^-1 in one go
+    constexpr bool YIN = FOLD && (SCALE || SKIPQ);
     const u32 n = blockIdx.x * TPB + threadIdx.x;
     const u32 H = N / 2;
     if (n >= (FOLD ? H : N)) return;
@@ -321,21 +325,26 @@ __global__ void __launch_bounds__(TPB) expand_kernel(const DevConsts *__restrict
     u64 x[NP][L], y[NP][M];
 #pragma unroll
     for (u32 i = 0; i < L; i++) {
-        if (FOLD)
+        if (YIN) {
+            const u64 q = dc->mod[i].q, u = pin[(size_t)i * N], v = pin[(size_t)i * N + H];
+            x[0][i] = mul_shoup(addmod(u, v, q), dc->fold_iaq[i], dc->fold_iaq_sh[i], q);
+            x[NP - 1][i] = mul_shoup(submod(u, v, q), dc->fold_ibq[i], dc->fold_ibq_sh[i], q);
+        } else if (FOLD) {
             fold_load(dc, i, pin[(size_t)i * N], pin[(size_t)i * N + H], x[0][i], x[NP - 1][i]);
-        else
+        } else {
             x[0][i] = pin[(size_t)i * N];
+        }
     }
 #pragma unroll
     for (int p = 0; p < NP; p++) {
         if (SCALE)
-            scale_pq_core<L, MAD>(dc, x[p], y[p]);
+            scale_pq_core<L, MAD, YIN>(dc, x[p], y[p]);
         else
-            expand_core<L, MAD>(dc, x[p], y[p]);
+            expand_core<L, MAD, YIN>(dc, x[p], y[p]);
     }
 #pragma unroll
     for (u32 a = 0; a < M; a++) {
-        if (!SCALE && a < L && skip_q) continue;  // the Q limbs already hold the operand's EVALUATION form (NttExtra)
+        if (!SCALE && a < L && SKIPQ) continue;  // (NttExtra)
         if (FOLD) {
             u64 y0, y1;
             fold_store(dc, a, y[0][a], y[NP - 1][a], y0, y1);
@@ -350,22 +359,23 @@ __global__ void __launch_bounds__(TPB) expand_kernel(const DevConsts *__restrict
 static void launch_expand_common(bool scale, bool fold, const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t so, size_t si,
                                  u32 n_outer, u64 *out, u32 out_polys, u32 out_slot, hipStream_t st, bool skip_q = false)
 {
-    const u32 sq = skip_q ? 1u : 0u;
     dim3 grid(((fold ? N / 2 : N) + TPB - 1) / TPB, n_outer * 2);
-#define EX(S_, F_, L_)                                                                                                     \
-    do {                                                                                                                   \
-        if (g_small_moduli)                                                                                                \
-            hipLaunchKernelGGL((expand_kernel<S_, F_, L_, true>), grid, dim3(TPB), 0, st, dc, N, in, so, si, out, out_polys, out_slot, sq); \
-        else                                                                                                               \
-            hipLaunchKernelGGL((expand_kernel<S_, F_, L_, false>), grid, dim3(TPB), 0, st, dc, N, in, so, si, out, out_polys, out_slot, sq); \
+#define EX(S_, F_, L_, Q_)                                                                                                    \
+    do {                                                                                                                      \
+        if (g_small_moduli)                                                                                                   \
+            hipLaunchKernelGGL((expand_kernel<S_, F_, L_, true, Q_>), grid, dim3(TPB), 0, st, dc, N, in, so, si, out, out_polys, out_slot); \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((expand_kernel<S_, F_, L_, false, Q_>), grid, dim3(TPB), 0, st, dc, N, in, so, si, out, out_polys, out_slot); \
     } while (0)
-#define EXL(L_)                                                   \
-    case L_:                                                      \
-        if (scale) {                                              \
-            if (fold) EX(true, true, L_); else EX(true, false, L_);   \
-        } else {                                                  \
-            if (fold) EX(false, true, L_); else EX(false, false, L_); \
-        }                                                         \
+#define EXL(L_)                                                         \
+    case L_:                                                            \
+        if (scale) {                                                    \
+            if (fold) EX(true, true, L_, false); else EX(true, false, L_, false); \
+        } else if (skip_q) {                                            \
+            if (fold) EX(false, true, L_, true); else EX(false, false, L_, true); \
+        } else {                                                        \
+            if (fold) EX(false, true, L_, false); else EX(false, false, L_, false); \
+        }                                                               \
         break;
     switch (L) { EXL(1) EXL(2) EXL(3) EXL(4) EXL(5) EXL(6) EXL(7) }
 #undef EXL

@@ -210,6 +210,10 @@ std::string HostParams::init(u32 N_, u32 L_, u64 t_, const u64 *q, const u64 *p)
         }
         for (u32 j = 0; j < L; j++) dc.qi_modqj[i][j] = qi % Q[j];
         dc.t_inv_modq[i] = invmod(t % qi, qi);
+        dc.fold_iaq[i] = mm(dc.fold_ia[i], dc.qhat_inv[i], qi);
+        dc.fold_iaq_sh[i] = shoup(dc.fold_iaq[i], qi);
+        dc.fold_ibq[i] = mm(dc.fold_ib[i], dc.qhat_inv[i], qi);
+        dc.fold_ibq_sh[i] = shoup(dc.fold_ibq[i], qi);
         dc.t_modq_sh[i] = shoup(t % qi, qi);
     }
     for (u32 j = 0; j < Lp; j++) {

@@ -44,6 +44,8 @@ struct DevConsts {
     u64 fold_w[MAX_M + 1], fold_w_sh[MAX_M + 1];    // forward: psi^{N/2} (twiddle of the stage with one group)
     u64 fold_ia[MAX_M + 1], fold_ia_sh[MAX_M + 1];  // inverse: N^-1            (sum branch)
     u64 fold_ib[MAX_M + 1], fold_ib_sh[MAX_M + 1];  // inverse: psi^{-N/2} N^-1 (difference branch)
+    // the same two constants times (Q/q_i)^-1: the CRT digit y_i of a base conversion straight from the folded load
+    u64 fold_iaq[8], fold_iaq_sh[8], fold_ibq[8], fold_ibq_sh[8];
     // client harness (encryption / decryption): t^-1 mod q_i, [Q]_t, Shoup companion of t mod q_i
     u64 t_inv_modq[8];
     u64 t_modq_sh[8];
