@@ -485,3 +485,51 @@ def test_run_pipelining_and_result_buffers(ob, pie, streams):
     for bf in bufs:
         assert (bf.cpu().numpy().view(np.uint64) == want).all()
     cc.close()
+
+
+# ---- caller-supplied moduli: the paths that the default 60-bit chain never takes ---------------------------------
+@pytest.mark.parametrize("N,L,t,below,what", [
+    (4096, 3, T32, (1 << 61) - 1, "61-bit primes: no lazy-residue NTT, no mad arithmetic"),
+    (4096, 2, T16, 1 << 50, "50-bit primes: register-blocked NTT, 128-bit Barrett instead of the one-word form"),
+    (16384, 2, T32, 1 << 58, "58-bit primes with the folded transforms"),
+])
+def test_caller_supplied_moduli(ob, pie, N, L, t, below, what):
+    """piehip_create with the context's own moduli (a deployment hands over OpenFHE's): tables, NTT,
+    base conversions, EvalMult and run() against the oracle built on the same moduli"""
+    ch = ob.gen_primes(N, 2 * L + 1, below)
+    q, p = ch[:L].copy(), ch[L:].copy()
+    o = ob.Oracle(N, L, t, q, p)
+    cc = pie.PieContext(N, L, t, q, p)
+    assert (cc.moduli == o.moduli).all()
+    rng = np.random.default_rng(N + L)
+    M = 2 * L + 1
+    x = rand_limbs(rng, o.moduli[:M], (2,), N)
+    f = cc.ntt(x, 0, M)
+    assert (f == np.stack([np.stack([o.ntt(mi, x[k, mi]) for mi in range(M)]) for k in range(2)])).all()
+    assert (cc.ntt(f, 0, M, inverse=True) == x).all()
+    xq = rand_limbs(rng, o.moduli[:L], (4,), N)
+    assert (cc.base_convert(0, xq) == np.stack([o.expand_q_to_qp(v) for v in xq])).all()
+    assert (cc.base_convert(1, xq) == np.stack([o.scale_pq_expand(v) for v in xq])).all()
+    xqp = rand_limbs(rng, o.moduli[:M], (3,), N)
+    assert (cc.base_convert(2, xqp) == np.stack([o.scale_round_tp(v) for v in xqp])).all()
+    sk = o.keygen(3)
+    evk = o.relin_keygen(sk, 4)
+    cc.load_relin_key(evk)
+    a = o.encrypt_slots(sk, [1, 2, 3, -4], 5)
+    b = o.encrypt_slots(sk, [5, -6, 7, 8], 6)
+    prod = cc.EvalMult(a, b)
+    assert (prod == o.mul(a, b, evk)).all()
+    assert list(o.decrypt_slots(sk, prod, 4)[0]) == [5, -12, 21, -32]
+    # a small query through run()
+    k, e, K, E, nb = 2, 6, 2, 5, 3
+    d = _query(ob, o, rng, 60, 6, k, e, K, E, nb)
+    db = np.stack([o.encode_eval(d["slots"][h, bn, j]) for h in range(K) for bn in range(nb) for j in range(E)]).reshape(K, nb, E, L, N)
+    masks = np.stack([o.encode_eval(d["mask_slots"][bn]) for bn in range(nb)])
+    idx = np.stack([o.encrypt_slots(sk, d["index"][h, j], 100 + h * E + j) for h in range(K) for j in range(E)]).reshape(K, E, 2, L, N)
+    minus = o.encrypt_slots(sk, d["minus"], 99)
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    op.setMinusCompareElement(minus)
+    op.setIndex(idx)
+    op.run()
+    assert (op.getResultList() == o.pie_run(idx, minus, db, masks, evk)).all()
+    cc.close()
