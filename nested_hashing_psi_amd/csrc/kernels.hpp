@@ -62,8 +62,8 @@ void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_
 void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
                     const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride = 0);
 
-// (process-wide switch, set from the context before its launches: all Q and P moduli are < 2^60, which lets the
-// base-conversion kernels use the carry-free v_mad_u64_u32 column accumulators)
+// (per-host-thread switch, set from the context before its launches: all Q and P moduli lie in (2^59, 2^60), which lets
+// the base-conversion and key-switch kernels use the carry-free v_mad_u64_u32 column accumulators and one-word Barrett)
 void set_small_moduli(bool v);
 
 // Base conversions, COEFFICIENT format.  Polynomial (o, c), o < n_outer, c < 2,

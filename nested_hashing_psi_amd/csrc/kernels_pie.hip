@@ -11,7 +11,9 @@ namespace piehip {
 
 static const u32 TPB = 256;
 
-static bool g_small_moduli = false;  // set per launch by the callers' context (all Q, P moduli < 2^60)
+// set by the calling context right before its launches (all Q, P moduli in (2^59, 2^60)); per host thread, so
+// contexts with different moduli can be driven from different threads
+static thread_local bool g_small_moduli = false;
 void set_small_moduli(bool v) { g_small_moduli = v; }
 
 // ---------------------------------------------------------------------------------------------
