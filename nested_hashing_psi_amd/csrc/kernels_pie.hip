@@ -4,6 +4,8 @@
 // encoding.  All are streaming u64 modular arithmetic: one thread per coefficient, consecutive
 // lanes on consecutive coefficients (coalesced 8-byte or 16-byte lanes), constants scalar-loaded
 // from one DevConsts block.  Reference call sites: BatchedFHEHIPPIE.cpp:101-127.
+#include <stdlib.h>
+
 #include "kernels.hpp"
 #include "madasm.h"
 
@@ -87,6 +89,9 @@ __global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *__restric
 // Same work with carry-free column accumulators on v_mad_u64_u32 (madasm.h): the 128-bit form above is bound by
 // its 64x64->128 multiplies (46 SIMD cycles each, 3.9 TB/s at C3), this one by HBM.  Needs every modulus
 // < 2^60 and E <= COLACC_MAX_TOTAL (one carry sweep after 8 terms keeps the columns from overflowing).
+#ifndef STAGE_A_PREFETCH
+#define STAGE_A_PREFETCH 1
+#endif
 template <int BPT, int CPT>
 __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
                                                           const u64 *__restrict__ idx, const u64 *__restrict__ minus,
@@ -103,6 +108,7 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
     const u64 *pi = idx + ((size_t)h * E) * 2 * LN + (size_t)l * N + n;
     const u64 *pd = db + (((size_t)h * bstride + beta0) * E) * LN + (size_t)l * N + n;  // db is [K][bstride][E][L][N]
     const size_t bin_stride = (size_t)E * LN;
+    constexpr bool PREFETCH = STAGE_A_PREFETCH != 0;
     ColAcc a[BPT][2][CPT];
 #pragma unroll
     for (int t = 0; t < BPT; t++)
@@ -110,40 +116,52 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int e = 0; e < CPT; e++) a[t][c][e] = ColAcc{0, 0, 0};
-    for (u32 j0 = 0; j0 < E; j0 += COLACC_MAX_TERMS) {
-        const u32 j1 = j0 + COLACC_MAX_TERMS < E ? j0 + COLACC_MAX_TERMS : E;
-        for (u32 j = j0; j < j1; j++) {
-            u64 iv[2][CPT], dv[BPT][CPT];
-            if (CPT == 2) {
-                const u64x2 i0 = *reinterpret_cast<const u64x2 *>(pi + (size_t)j * 2 * LN);
-                const u64x2 i1 = *reinterpret_cast<const u64x2 *>(pi + (size_t)j * 2 * LN + LN);
-                iv[0][0] = i0.x, iv[0][CPT - 1] = i0.y, iv[1][0] = i1.x, iv[1][CPT - 1] = i1.y;
+    // operands of term j: loaded one term ahead (2 + BPT independent streams per thread; without the prefetch a wave
+    // alternates between waiting for them and ~110 mads, and three waves per SIMD do not cover the HBM latency)
+    u64 iv[2][CPT], dv[BPT][CPT], niv[2][CPT], ndv[BPT][CPT];
+    auto load_term = [&](u32 j, u64 (&vi)[2][CPT], u64 (&vd)[BPT][CPT]) {
+        if (CPT == 2) {
+            const u64x2 i0 = *reinterpret_cast<const u64x2 *>(pi + (size_t)j * 2 * LN);
+            const u64x2 i1 = *reinterpret_cast<const u64x2 *>(pi + (size_t)j * 2 * LN + LN);
+            vi[0][0] = i0.x, vi[0][CPT - 1] = i0.y, vi[1][0] = i1.x, vi[1][CPT - 1] = i1.y;
 #pragma unroll
-                for (int t = 0; t < BPT; t++) {
-                    const u64x2 d = *reinterpret_cast<const u64x2 *>(pd + (size_t)t * bin_stride + (size_t)j * LN);
-                    dv[t][0] = d.x, dv[t][CPT - 1] = d.y;
-                }
-            } else {
-                iv[0][0] = pi[(size_t)j * 2 * LN];
-                iv[1][0] = pi[(size_t)j * 2 * LN + LN];
-#pragma unroll
-                for (int t = 0; t < BPT; t++) dv[t][0] = pd[(size_t)t * bin_stride + (size_t)j * LN];
+            for (int t = 0; t < BPT; t++) {
+                const u64x2 d = *reinterpret_cast<const u64x2 *>(pd + (size_t)t * bin_stride + (size_t)j * LN);
+                vd[t][0] = d.x, vd[t][CPT - 1] = d.y;
             }
-            Split30 is[2][CPT];
+        } else {
+            vi[0][0] = pi[(size_t)j * 2 * LN];
+            vi[1][0] = pi[(size_t)j * 2 * LN + LN];
 #pragma unroll
-            for (int c = 0; c < 2; c++)
-#pragma unroll
-                for (int e = 0; e < CPT; e++) is[c][e] = split30(iv[c][e]);
-#pragma unroll
-            for (int t = 0; t < BPT; t++)
-#pragma unroll
-                for (int e = 0; e < CPT; e++) {
-                    const Split30 ds = split30(dv[t][e]);
-                    colacc_mac(a[t][0][e], is[0][e], ds);
-                    colacc_mac(a[t][1][e], is[1][e], ds);
-                }
+            for (int t = 0; t < BPT; t++) vd[t][0] = pd[(size_t)t * bin_stride + (size_t)j * LN];
         }
-        if (j1 < E) {  // another chunk follows: make room in the low columns
+    };
+    load_term(0, niv, ndv);
+    for (u32 j = 0; j < E; j++) {
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int e = 0; e < CPT; e++) iv[c][e] = niv[c][e];
+#pragma unroll
+        for (int t = 0; t < BPT; t++)
+#pragma unroll
+            for (int e = 0; e < CPT; e++) dv[t][e] = ndv[t][e];
+        if (PREFETCH && j + 1 < E) load_term(j + 1, niv, ndv);
+        Split30 is[2][CPT];
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int e = 0; e < CPT; e++) is[c][e] = split30(iv[c][e]);
+#pragma unroll
+        for (int t = 0; t < BPT; t++)
+#pragma unroll
+            for (int e = 0; e < CPT; e++) {
+                const Split30 ds = split30(dv[t][e]);
+                colacc_mac(a[t][0][e], is[0][e], ds);
+                colacc_mac(a[t][1][e], is[1][e], ds);
+            }
+        if (!PREFETCH && j + 1 < E) load_term(j + 1, niv, ndv);
+        if ((j % COLACC_MAX_TERMS) == COLACC_MAX_TERMS - 1 && j + 1 < E) {  // more terms follow: make room in the low columns
 #pragma unroll
             for (int t = 0; t < BPT; t++)
 #pragma unroll
@@ -171,7 +189,8 @@ void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, cons
     const bool mad = small_moduli && E <= COLACC_MAX_TOTAL;
     const int cap = mad ? 7 : 8;
     int bpt = 1;
-    for (int c = cap; c >= 1; c--)
+    static const int cap_env = [] { const char *e = getenv("PIEHIP_BPT_CAP"); return e ? atoi(e) : 0; }();  // experiments
+    for (int c = (cap_env > 0 && cap_env < cap) ? cap_env : cap; c >= 1; c--)
         if (b % c == 0) {
             bpt = c;
             break;
