@@ -89,9 +89,10 @@ void launch_digits(const DevConsts *dc, u32 N, u32 L, const u64 *d2, size_t stri
 // out[bin][c][j] = (d01[bin][c][j] + sum_i dig[bin][i][j] (.) key[i][c][j]) (.) mask[bin][j]   (mask may be null)
 // out_map (may be null): coefficient n of the result is written to position out_map[n] (lane order -> standard)
 // key_group > 1: ciphertext `bin` uses key + (bin % key_group) * key_stride (EvalMerge: one rotation key per position)
+// sigma_T != 0: out_map is ntt_sigma_inverse_map of a transform with sigma_T threads per slice; stores go through an LDS tile
 void launch_relin_mac(const DevConsts *dc, u32 N, u32 L, const u64 *d01, size_t stride01, const u64 *dig, const u64 *key,
                       const u64 *mask, u64 *out, u32 nb, hipStream_t st, const u32 *out_map = nullptr, size_t key_stride = 0,
-                      u32 key_group = 1);
+                      u32 key_group = 1, u32 sigma_T = 0);
 // rotation-based PIE (FHEHIPPIE.cpp:61-77), see kernels_pie.hip
 void launch_bcast_mul_plain(const DevConsts *dc, u32 N, u32 L, const u64 *x, size_t xs, u32 group, const u64 *pt, size_t ps_outer,
                             size_t ps_inner, u64 *out, u32 nct, hipStream_t st);

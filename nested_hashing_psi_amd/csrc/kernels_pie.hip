@@ -569,14 +569,26 @@ void launch_digits(const DevConsts *dc, u32 N, u32 L, const u64 *d2, size_t stri
 
 // One thread: two adjacent coefficients (16-byte lanes) of one (bin, limb j), both ciphertext components, so a
 // digit is loaded once for its two key products.  out_map (lane order -> standard) keeps pairs adjacent.
-template <bool MAD>
+// TILE (lane-ordered inputs of the register-blocked transform, T = threads per slice): a block takes the 16 x 16 pairs
+// (thread tau0..tau0+15 of the transform) x (pair k = 0..15), i.e. sixteen 256-byte runs of the lane order, and hands the
+// results through LDS so that they leave as one contiguous 4 KiB run of the standard order (pair 16 tau + k); with the
+// plain out_map scatter every 16-byte store lands in its own 256-byte stretch.
+template <bool MAD, bool TILE>
 __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, const u64 *__restrict__ d01,
                                                         size_t stride01, const u64 *__restrict__ dig,
                                                         const u64 *__restrict__ key0, const u64 *__restrict__ mask,
                                                         u64 *__restrict__ out, const u32 *__restrict__ out_map,
-                                                        size_t key_stride, u32 key_group)
+                                                        size_t key_stride, u32 key_group, u32 T)
 {
-    const u32 n = 2 * (blockIdx.x * TPB + threadIdx.x);
+    __shared__ u64x2 s_tile[TILE ? 2 : 1][TILE ? TPB : 1];
+    u32 n = 2 * (blockIdx.x * TPB + threadIdx.x);
+    u32 std_pair = 0;  // TILE: first standard-order pair of this block's tile
+    if (TILE) {
+        const u32 tiles = T / 16, slice = blockIdx.x / tiles, tau0 = (blockIdx.x % tiles) * 16;
+        const u32 k = threadIdx.x >> 4, tt = threadIdx.x & 15;
+        n = 2 * (slice * 16 * T + k * T + tau0 + tt);
+        std_pair = slice * 16 * T + 16 * tau0;
+    }
     if (n >= N) return;
     const u32 j = blockIdx.y, bin = blockIdx.z;
     const u64 *key = key0 + (size_t)(bin % key_group) * key_stride;  // one key per position in a group (EvalMerge)
@@ -616,7 +628,7 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restr
     }
     u64x2 mk;
     if (mask) mk = *reinterpret_cast<const u64x2 *>(mask + (size_t)bin * LN + (size_t)j * N + n);
-    const u32 po = out_map ? out_map[n] : n;
+    const u32 po = TILE ? 0 : (out_map ? out_map[n] : n);
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         const u64x2 s = *reinterpret_cast<const u64x2 *>(d01 + (size_t)bin * stride01 + (size_t)c * LN + (size_t)j * N + n);
@@ -627,20 +639,35 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restr
             r.x = mulmod(r.x, mk.x, m);
             r.y = mulmod(r.y, mk.y, m);
         }
-        *reinterpret_cast<u64x2 *>(out + ((size_t)bin * 2 + c) * LN + (size_t)j * N + po) = r;
+        if (TILE)
+            s_tile[c][16 * (threadIdx.x & 15) + (threadIdx.x >> 4)] = r;  // standard offset inside the tile: 16 (tau - tau0) + k
+        else
+            *reinterpret_cast<u64x2 *>(out + ((size_t)bin * 2 + c) * LN + (size_t)j * N + po) = r;
+    }
+    if (TILE) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+            *reinterpret_cast<u64x2 *>(out + ((size_t)bin * 2 + c) * LN + (size_t)j * N + 2 * (std_pair + threadIdx.x)) = s_tile[c][threadIdx.x];
     }
 }
 void launch_relin_mac(const DevConsts *dc, u32 N, u32 L, const u64 *d01, size_t stride01, const u64 *dig, const u64 *key,
-                      const u64 *mask, u64 *out, u32 nb, hipStream_t st, const u32 *out_map, size_t key_stride, u32 key_group)
+                      const u64 *mask, u64 *out, u32 nb, hipStream_t st, const u32 *out_map, size_t key_stride, u32 key_group,
+                      u32 sigma_T)
 {
     dim3 grid((N / 2 + TPB - 1) / TPB, L, nb);
     if (!key_group) key_group = 1;
-    if (g_small_moduli)
-        hipLaunchKernelGGL(relin_mac_kernel<true>, grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map,
-                           key_stride, key_group);
-    else
-        hipLaunchKernelGGL(relin_mac_kernel<false>, grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map,
-                           key_stride, key_group);
+    // sigma_T: out_map is the lane order of the register-blocked transform with sigma_T threads per slice
+    const bool tile = out_map && sigma_T >= 16 && sigma_T % 16 == 0 && (N / 2) % TPB == 0;
+#define RM(M_, T_)                                                                                                              \
+    hipLaunchKernelGGL((relin_mac_kernel<M_, T_>), grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map, \
+                       key_stride, key_group, sigma_T)
+    if (g_small_moduli) {
+        if (tile) RM(true, true); else RM(true, false);
+    } else {
+        if (tile) RM(false, true); else RM(false, false);
+    }
+#undef RM
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -87,6 +87,7 @@ struct piehip_ctx {
     bool fold_on = false;     // outermost NTT stage folded into the coefficient-wise kernels (N >= 2^14)
     u32 *d_inv_pos = nullptr; // EVALUATION position -> slot
     u32 *d_sigma_inv = nullptr;  // lane-order position -> standard position (identity for small rings)
+    u32 sigma_T = 0;             // threads per slice of the transform that defines the lane order (slice size / 32)
     bool small_moduli = false;   // all Q and P moduli in (2^59, 2^60): v_mad_u64_u32 column accumulators, one-word Barrett
     bool sigma_on = false;       // the register-blocked NTT (and hence the lane order) applies to this context
     u64 *d_evk_sigma = nullptr, *d_masks_sigma = nullptr;  // lane-ordered copies of key and masks
@@ -272,7 +273,8 @@ static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, c
         if (h->wait_before_results && out_is_result) (void)hipStreamWaitEvent(h->stream, h->wait_before_results, 0);
         ProfScope ps(h, PIEHIP_K_RELIN, W * (nb * ((double)L * L + 2 * L + 2 * L + (mask ? L : 0)) + 2.0 * L * L));
         launch_relin_mac(h->d_dc, N, L, w.d01, 2 * LN, w.dig, key, mask, out, nb, h->stream,
-                         (sigma && h->sigma_on) ? h->d_sigma_inv : nullptr, key_stride, key_group);
+                         (sigma && h->sigma_on) ? h->d_sigma_inv : nullptr, key_stride, key_group,
+                         (sigma && h->sigma_on) ? h->sigma_T : 0);
     }
 }
 
@@ -456,6 +458,10 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
             return fail(PIEHIP_EHIP, "sigma map upload failed");
         }
         h->sigma_on = h->d_twc != nullptr;
+        if (h->sigma_on) {
+            const u32 s0 = h->fold_on ? 1u : ntt_fast_s0(h->hp.logN);
+            h->sigma_T = (N >> s0) / 32;
+        }
         h->small_moduli = true;
         for (u32 a = 0; a < M; a++)
             if ((h->hp.moduli[a] >> 59) != 1) h->small_moduli = false;  // the mad paths assume 2^59 < q < 2^60
