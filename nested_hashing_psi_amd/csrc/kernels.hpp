@@ -28,12 +28,14 @@ u32 ntt_fast_s0(u32 logN);  // log2 slices per limb the fast kernel would use, o
 // Optional extras of the register-blocked kernel (ciphertext multiplication, kernels_ntt_fast.hip):
 //   inverse, standard order in:  limbs [nb][copy_K][2][copy_L]; the lane-ordered EVALUATION input of operand 0 of every
 //                                bin is also written to the Q limbs of copy_out[nb][4][copy_M][N] (slots 0, 1)
+//   forward, lane order:         lazy_out -- no final normalisation
 //   forward:                     nlimbs counts a compact enumeration of [nb][4][skip_M] that omits limbs < skip_L of
 //                                slots 0 and 1 (they already hold EVALUATION data)
 struct NttExtra {
     u64 *copy_out = nullptr;
     u32 copy_K = 1, copy_L = 1, copy_M = 1;
     u32 skip_L = 0, skip_M = 0;
+    bool lazy_out = false;  // forward, lane order: leave the residues in [0, 8q) (the consumer reduces anyway)
 };
 bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
                      u32 mod_count, bool inverse, bool sigma, u32 num_cus, hipStream_t st, const u64 *lift_src = nullptr,

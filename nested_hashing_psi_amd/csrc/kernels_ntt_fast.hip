@@ -209,7 +209,9 @@ __device__ __forceinline__ u64 lift_digit(u64 v, u64 qi, u64 qi_mod_qj, const Mo
     return r;
 }
 
-template <int LOGN, bool INV, bool SIGMA>
+// LAZY (forward, lane order): residues leave in [0, 8q) instead of [0, q) -- for consumers that reduce anyway (the
+// tensor product's 128-bit Barrett, the key-switch MAC's accumulator); saves three conditional subtractions per coefficient
+template <int LOGN, bool INV, bool SIGMA, bool LAZY = false>
 __global__ void __launch_bounds__((1 << LOGN) / 32)
 ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u64x2 *__restrict__ gtwc,
                 const DevConsts *__restrict__ gdc, NttFastArgs a)
@@ -397,12 +399,16 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
                 for (int k = 0; k < 16; k++) {
                     u64x2 v;
                     u64 r0 = x[2 * k], r1 = x[2 * k + 1];
-                    r0 = r0 >= q4 ? r0 - q4 : r0;
-                    r1 = r1 >= q4 ? r1 - q4 : r1;
-                    r0 = r0 >= q2 ? r0 - q2 : r0;
-                    r1 = r1 >= q2 ? r1 - q2 : r1;
-                    v.x = r0 >= q ? r0 - q : r0;
-                    v.y = r1 >= q ? r1 - q : r1;
+                    if (!LAZY) {
+                        r0 = r0 >= q4 ? r0 - q4 : r0;
+                        r1 = r1 >= q4 ? r1 - q4 : r1;
+                        r0 = r0 >= q2 ? r0 - q2 : r0;
+                        r1 = r1 >= q2 ? r1 - q2 : r1;
+                        r0 = r0 >= q ? r0 - q : r0;
+                        r1 = r1 >= q ? r1 - q : r1;
+                    }
+                    v.x = r0;
+                    v.y = r1;
                     // lane order of a limb transformed as 2^sigma_split slices: slice tau / Ts, thread tau % Ts
                     const u32 Ts = T >> a.sigma_split;
                     *reinterpret_cast<u64x2 *>(g + (size_t)(tau / Ts) * (n >> a.sigma_split) + 2 * (k * Ts + tau % Ts)) = v;
@@ -553,18 +559,18 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
     }
 }
 
-template <int LOGN, bool INV, bool SIGMA>
+template <int LOGN, bool INV, bool SIGMA, bool LAZY = false>
 static void launch_one(const NttFastArgs &a, u32 max_groups, hipStream_t st)
 {
     constexpr u32 n = 1u << LOGN;
     constexpr size_t lds = (size_t)(n + n / 16) * sizeof(u64);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void *)ntt_fast_kernel<LOGN, INV, SIGMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)ntt_fast_kernel<LOGN, INV, SIGMA, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     u32 grid = a.nitems < max_groups ? a.nitems : max_groups;
-    hipLaunchKernelGGL((ntt_fast_kernel<LOGN, INV, SIGMA>), dim3(grid), dim3(n / 32), lds, st, a.data, reinterpret_cast<const u64x2 *>(a.twp), reinterpret_cast<const u64x2 *>(a.twc), a.dc, a);
+    hipLaunchKernelGGL((ntt_fast_kernel<LOGN, INV, SIGMA, LAZY>), dim3(grid), dim3(n / 32), lds, st, a.data, reinterpret_cast<const u64x2 *>(a.twp), reinterpret_cast<const u64x2 *>(a.twc), a.dc, a);
 }
 
 // returns false if this slice size has no register-blocked kernel
@@ -635,6 +641,7 @@ bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N,
     a.copy_M = ex ? ex->copy_M : 1;
     a.skip_L = (ex && !inverse) ? ex->skip_L : 0;
     a.skip_M = ex ? ex->skip_M : 0;
+    const bool lazy = ex && ex->lazy_out && !inverse && sigma && !a.lift_L;
     // resident workgroups per CU by LDS: 136 KiB -> 1, 68 KiB -> 2, 34 KiB -> 4
     const u32 per_cu = logn == 14 ? 1 : (logn == 13 ? 2 : 4);
     const u32 maxg = num_cus * per_cu;
@@ -644,7 +651,8 @@ bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N,
             if (sigma) launch_one<LG, true, true>(a, maxg, st);                   \
             else launch_one<LG, true, false>(a, maxg, st);                        \
         } else {                                                                  \
-            if (sigma) launch_one<LG, false, true>(a, maxg, st);                  \
+            if (sigma && lazy) launch_one<LG, false, true, true>(a, maxg, st);    \
+            else if (sigma) launch_one<LG, false, true>(a, maxg, st);             \
             else launch_one<LG, false, false>(a, maxg, st);                       \
         }                                                                         \
     } while (0)

@@ -633,8 +633,11 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restr
     for (int c = 0; c < 2; c++) {
         const u64x2 s = *reinterpret_cast<const u64x2 *>(d01 + (size_t)bin * stride01 + (size_t)c * LN + (size_t)j * N + n);
         u64x2 r;
-        r.x = addmod(MAD ? reduce123(acc[c][0], m) : reduce128(acc[c][0], m), s.x, m.q);  // L <= 7 products
-        r.y = addmod(MAD ? reduce123(acc[c][1], m) : reduce128(acc[c][1], m), s.y, m.q);
+        // d01 joins the sum before the reduction: it may arrive unnormalised (< 2^63) from the forward transform
+        add128(acc[c][0], U128{s.x, 0});
+        add128(acc[c][1], U128{s.y, 0});
+        r.x = MAD ? reduce123(acc[c][0], m) : reduce128(acc[c][0], m);  // L <= 7 products + a 63-bit term
+        r.y = MAD ? reduce123(acc[c][1], m) : reduce128(acc[c][1], m);
         if (mask) {
             r.x = mulmod(r.x, mk.x, m);
             r.y = mulmod(r.y, mk.y, m);

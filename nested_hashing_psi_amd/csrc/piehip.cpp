@@ -295,13 +295,14 @@ static void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const 
         launch_scale_pq_expand(h->d_dc, N, L, y, sy, LN, nb, w.eqp, 4, 2, h->stream, h->fold_on);
     }
     // the QP operands and the tensor result never leave the library: lane order, no LDS transposes
-    if (xq_ready) {
+    {
         NttExtra ex;
-        ex.skip_L = L;
-        ex.skip_M = M;
-        ntt(h, w.eqp, nb * (4 * M - 2 * L), 0, M, false, true, true, &ex);
-    } else {
-        ntt(h, w.eqp, nb * 4 * M, 0, M, false, true, true);
+        ex.lazy_out = true;  // the tensor product's Barrett reduction takes any operands < 2^63
+        if (xq_ready) {
+            ex.skip_L = L;
+            ex.skip_M = M;
+        }
+        ntt(h, w.eqp, nb * (xq_ready ? 4 * M - 2 * L : 4 * M), 0, M, false, true, true, &ex);
     }
     {
         ProfScope ps(h, PIEHIP_K_TENSOR, W * nb * 7.0 * M);
@@ -313,7 +314,11 @@ static void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const 
             ProfScope ps(h, PIEHIP_K_SCALE, W * nb * (3.0 * M + 3.0 * L));
             launch_scale_round(h->d_dc, N, L, w.dqp, nb, w.d01, 2 * LN, w.d2c, LN, h->stream, h->fold_on, false);
         }
-        ntt(h, w.d01, nb * 2 * L, 0, L, false, true, true);
+        {
+            NttExtra ex;
+            ex.lazy_out = true;  // the key-switch MAC adds d01 into its accumulator before reducing
+            ntt(h, w.d01, nb * 2 * L, 0, L, false, true, true, &ex);
+        }
         enqueue_keyswitch(h, w, nb, h->sigma_on ? h->d_evk_sigma : h->d_evk, mask, out, true, true, 0, 1, out_is_result);
     } else {
         {
