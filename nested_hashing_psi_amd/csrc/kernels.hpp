@@ -36,6 +36,7 @@ struct NttExtra {
     u32 copy_K = 1, copy_L = 1, copy_M = 1;
     u32 skip_L = 0, skip_M = 0;
     bool lazy_out = false;  // forward, lane order: leave the residues in [0, 8q) (the consumer reduces anyway)
+    bool folded = false;    // set by launch_ntt(.., folded): inverse transforms then hand over unnormalised [0, 4q) residues
 };
 bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
                      u32 mod_count, bool inverse, bool sigma, u32 num_cus, hipStream_t st, const u64 *lift_src = nullptr,

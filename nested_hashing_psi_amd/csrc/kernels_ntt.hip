@@ -159,8 +159,11 @@ void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_
 {
     if (!nlimbs) return;
     if (folded) {  // two half-size slices per limb, outer stage done by the neighbouring kernels
+        NttExtra exf;
+        if (ex) exf = *ex;
+        exf.folded = true;
         (void)launch_ntt_fast(pl.twp, pl.twc_fold, pl.dc, pl.N, pl.logN, 1, data, nlimbs, mod_base, mod_count, inverse, sigma,
-                              pl.num_cus, st, nullptr, 0, 0, ex);
+                              pl.num_cus, st, nullptr, 0, 0, &exf);
         return;
     }
     NttArgs a;

@@ -56,6 +56,7 @@ struct NttFastArgs {
     u32 copy_K, copy_L, copy_M;
     // forward: the transformed limbs are a compact enumeration of [nb][4][skip_M] without limbs < skip_L of slots 0, 1
     u32 skip_L, skip_M;
+    u32 folded;  // s0 != 0 because the caller's neighbouring kernels apply the outermost stage (not the global-memory stages)
 };
 
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
@@ -546,7 +547,11 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
                 if (a.s0 == 0) {
                     v.x = mul_shoup(x[2 * k], m.n_inv, m.n_inv_sh, q);
                     v.y = mul_shoup(x[2 * k + 1], m.n_inv, m.n_inv_sh, q);
-                } else {
+                } else if (a.folded) {  // the consumer applies the outermost stage and N^-1 with a Shoup product, which
+                                        // takes the unnormalised [0, 4q) residues as they are (kernels_pie.hip fold_load)
+                    v.x = x[2 * k];
+                    v.y = x[2 * k + 1];
+                } else {  // split transform of a ring above 2^14: the global-memory stages expect canonical residues
                     u64 r0 = x[2 * k], r1 = x[2 * k + 1];
                     r0 = r0 >= q2 ? r0 - q2 : r0;
                     r1 = r1 >= q2 ? r1 - q2 : r1;
@@ -641,6 +646,7 @@ bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N,
     a.copy_M = ex ? ex->copy_M : 1;
     a.skip_L = (ex && !inverse) ? ex->skip_L : 0;
     a.skip_M = ex ? ex->skip_M : 0;
+    a.folded = (ex && ex->folded) ? 1u : 0u;
     const bool lazy = ex && ex->lazy_out && !inverse && sigma && !a.lift_L;
     // resident workgroups per CU by LDS: 136 KiB -> 1, 68 KiB -> 2, 34 KiB -> 4
     const u32 per_cu = logn == 14 ? 1 : (logn == 13 ? 2 : 4);

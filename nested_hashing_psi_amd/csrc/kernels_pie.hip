@@ -256,18 +256,21 @@ __device__ __forceinline__ u64 crt_out(const u64 *y, const u64 *hat, u32 hat_str
 // coefficients n and n + N/2 of every limb pass through registers anyway:
 //   load side  (input comes from an inverse transform):  (u, v) -> ((u + v) N^-1, (u - v) psi^{-N/2} N^-1)
 //   store side (output goes to a forward transform):     (u, v) -> (u + v psi^{N/2}, u - v psi^{N/2})
+// The folded inverse transform hands over unnormalised residues in [0, 4q) and the forward transform takes anything
+// below 8q, so neither side reduces sums or differences: the Shoup product accepts any 64-bit operand.
 __device__ __forceinline__ void fold_load(const DevConsts *dc, u32 a, u64 u, u64 v, u64 &x0, u64 &x1)
 {
     const u64 q = dc->mod[a].q;
-    x0 = mul_shoup(addmod(u, v, q), dc->fold_ia[a], dc->fold_ia_sh[a], q);
-    x1 = mul_shoup(submod(u, v, q), dc->fold_ib[a], dc->fold_ib_sh[a], q);
+    x0 = mul_shoup(u + v, dc->fold_ia[a], dc->fold_ia_sh[a], q);
+    x1 = mul_shoup(u + (4 * q - v), dc->fold_ib[a], dc->fold_ib_sh[a], q);
 }
+// u canonical; results in (0, 3q)
 __device__ __forceinline__ void fold_store(const DevConsts *dc, u32 a, u64 u, u64 v, u64 &y0, u64 &y1)
 {
     const u64 q = dc->mod[a].q;
-    const u64 t = mul_shoup(v, dc->fold_w[a], dc->fold_w_sh[a], q);
-    y0 = addmod(u, t, q);
-    y1 = submod(u, t, q);
+    const u64 t = mul_shoup_lazy(v, dc->fold_w[a], dc->fold_w_sh[a], q);  // [0, 2q)
+    y0 = u + t;
+    y1 = u + (2 * q - t);
 }
 
 // The RNS width L is a template parameter: with run-time trip counts hipcc indexes the per-coefficient residue
@@ -348,8 +351,8 @@ __global__ void __launch_bounds__(TPB) expand_kernel(const DevConsts *__restrict
     for (u32 i = 0; i < L; i++) {
         if (YIN) {
             const u64 q = dc->mod[i].q, u = pin[(size_t)i * N], v = pin[(size_t)i * N + H];
-            x[0][i] = mul_shoup(addmod(u, v, q), dc->fold_iaq[i], dc->fold_iaq_sh[i], q);
-            x[NP - 1][i] = mul_shoup(submod(u, v, q), dc->fold_ibq[i], dc->fold_ibq_sh[i], q);
+            x[0][i] = mul_shoup(u + v, dc->fold_iaq[i], dc->fold_iaq_sh[i], q);            // u, v in [0, 4q)
+            x[NP - 1][i] = mul_shoup(u + (4 * q - v), dc->fold_ibq[i], dc->fold_ibq_sh[i], q);
         } else if (FOLD) {
             fold_load(dc, i, pin[(size_t)i * N], pin[(size_t)i * N + H], x[0][i], x[NP - 1][i]);
         } else {
