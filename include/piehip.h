@@ -104,6 +104,9 @@ int piehip_tabulation_hash(uint64_t hash_seed, uint32_t nfun, uint32_t hf, const
  * setMinusCompareElement (BatchedFHEHIPPIE.hpp:45-48): minus[2][L][N]. */
 int piehip_set_index(piehip_handle h, const uint64_t *idx);
 int piehip_set_minus(piehip_handle h, const uint64_t *minus);
+/* the same for inputs that already live in HBM (no copy is taken).  The arrays must have been written on the stream
+ * given to piehip_create, or be complete, at the time of the call; call again whenever their contents change, so that
+ * the next run() waits for the writer (see "Stream order" below). */
 int piehip_set_index_device(piehip_handle h, const void *d_idx);
 int piehip_set_minus_device(piehip_handle h, const void *d_minus);
 
