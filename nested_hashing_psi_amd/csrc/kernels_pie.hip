@@ -189,8 +189,7 @@ void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, cons
     const bool mad = small_moduli && E <= COLACC_MAX_TOTAL;
     const int cap = mad ? 7 : 8;
     int bpt = 1;
-    static const int cap_env = [] { const char *e = getenv("PIEHIP_BPT_CAP"); return e ? atoi(e) : 0; }();  // experiments
-    for (int c = (cap_env > 0 && cap_env < cap) ? cap_env : cap; c >= 1; c--)
+    for (int c = cap; c >= 1; c--)
         if (b % c == 0) {
             bpt = c;
             break;

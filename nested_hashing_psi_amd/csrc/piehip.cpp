@@ -240,11 +240,7 @@ static void ntt(piehip_ctx *h, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_coun
 // The X operand of a ciphertext multiplication is available in EVALUATION format before its inverse transform; when
 // the register-blocked kernel runs that transform it also drops a lane-ordered copy into the Q limbs of the QP operand
 // array, and the forward transform over QP skips those limbs (8 of 36 per bin layer at L = 4).
-static bool xq_reuse(const piehip_ctx *h)
-{
-    static const bool off = [] { const char *e = getenv("PIEHIP_XQ"); return e && e[0] == '0'; }();  // experiments
-    return !off && h->sigma_on && ntt_supports_extra(h->plan, h->fold_on);
-}
+static bool xq_reuse(const piehip_ctx *h) { return h->sigma_on && ntt_supports_extra(h->plan, h->fold_on); }
 
 // BV key switch of the COEFFICIENT-format polynomials at w.d2c with `key`, added to the EVALUATION
 // ciphertexts at w.d01, optionally multiplied by mask plaintexts: out[nb][2][L][N]
