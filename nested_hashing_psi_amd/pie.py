@@ -243,6 +243,8 @@ class BatchedFHEHIPPIE:
                 raise ValueError("slot value out of range for the plaintext modulus")
             _check(lib().piehip_load_db_slots(h, self.K, self.b, self.E, B, s.ctypes.data_as(i64p), m.ctypes.data_as(i64p)))
         self._keep = []
+        self._results = np.empty((self.b, 2, self.cc.L, self.cc.N), dtype=np.uint64)  # touched now, in the offline phase
+        self._results.fill(0)
 
     def hashTable(self):
         """hierarchicalCuckooTable after the bin shuffle, [k][e][K][b][E] (only after a serverSet build)"""
@@ -285,7 +287,13 @@ class BatchedFHEHIPPIE:
         _check(lib().piehip_sync(self.cc._h))
 
     def getResultList(self):
-        out = np.zeros((self.b, 2, self.cc.L, self.cc.N), dtype=np.uint64)
+        """the b result ciphertexts.  As in the reference (BatchedFHEHIPPIE.hpp:35-38 returns a reference to the member
+        vector) the array belongs to the operator and is overwritten by the next call; copy it to keep it.  (A fresh
+        14 MiB numpy array per query costs ~25 ms of first-touch page faults under the device-to-host copy.)"""
+        if getattr(self, "_results", None) is None:
+            self._results = np.empty((self.b, 2, self.cc.L, self.cc.N), dtype=np.uint64)
+            self._results.fill(0)
+        out = self._results
         _check(lib().piehip_get_results(self.cc._h, out.ctypes.data_as(u64p)))
         return out
 
