@@ -595,6 +595,12 @@ static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E)
     if (K < 2) return fail(PIEHIP_EINVAL, "Cuckoo Table needs more than one hash function!");  // CuckooHashTable.cpp:39-42
     if (b < 1 || E < 1) return fail(PIEHIP_EINVAL, "Bin size needs to be at least of size one!");
     const size_t LN = h->LN();
+    if (h->K == K && h->b == b && h->E == E && h->d_db && h->d_masks && h->d_acc && h->d_out && h->ws.nb == b) {
+        // same shape as the database being replaced: keep the 0.5 GiB of buffers (hipFree + hipMalloc cost ~10 ms)
+        dev_free(&h->d_idx_own);
+        h->d_idx = nullptr;
+        return PIEHIP_OK;
+    }
     dev_free(&h->d_db);
     dev_free(&h->d_masks);
     dev_free(&h->d_masks_sigma);
