@@ -46,7 +46,7 @@ def uniform_limbs(torch, shape_prefix, moduli, N, device, gen):
     return out
 
 
-def cpu_baseline(cfg, seconds_target=12.0):
+def cpu_baseline(cfg, seconds_target=12.0, max_threads=16):
     """The oracle (a CPU restatement of the reference path -- OpenFHE itself is not available)
     timed on this host, one core, on a bounded sample of the same workload."""
     from oracle import binding as ob
@@ -76,6 +76,19 @@ def cpu_baseline(cfg, seconds_target=12.0):
     out = {"value": done / dt, "unit": "ciphertexts/s", "cores": 1, "kind": "port",
            "sample": "%d bin layers of the %s workload (K=%d, E=%d; 1 ct x ct + %d ct x pt MACs each), %.1f s; "
                      "CPU restatement in C (oracle/), OpenFHE not available" % (done, cfg["name"], K, E, K * E, dt)}
+    # (b) of SURVEY 8d: the same work on every core this process may use, one bin layer per task (bin layers are
+    # independent; the C call releases the GIL)
+    import concurrent.futures
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, max_threads)  # the GPU box grants a one-GPU job 16 CPUs' worth of time whatever the affinity mask says
+    if cores > 1:
+        ntask = int(max(cores, min(64 * b, 0.5 * seconds_target / per_bin * cores)))
+        t0 = time.perf_counter()
+        with concurrent.futures.ThreadPoolExecutor(max_workers=cores) as pool:
+            list(pool.map(lambda _: o.pie_run(idx, minus, db1, m1, evk), range(ntask)))
+        dtp = time.perf_counter() - t0
+        out["all_cores"] = {"value": ntask / dtp, "unit": "ciphertexts/s", "cores": cores,
+                            "sample": "%d bin layers on %d threads, %.1f s" % (ntask, cores, dtp)}
     # the same end-to-end PSI as e2e_psi(), every phase on one host core (encode of the K*b*E+b plaintexts
     # extrapolated from a sample of 16 to keep this leg bounded)
     k, e, nS, nC = cfg["k"], cfg["e"], cfg["S"], cfg["C"]
@@ -159,6 +172,16 @@ def e2e_psi(cfg, pie, cc, device_sync):
     return out
 
 
+def alg_bytes_run(cfg):
+    """algorithmic bytes of one run() by the unfused limb-pass formulas of SURVEY.md 8d (reference schedule)"""
+    N, L, K, E, b = cfg["N"], cfg["L"], cfg["K"], cfg["E"], cfg["b"]
+    W, M = 8 * N, 2 * L + 1
+    stage_a = (b * K * E * L + K * E * 2 * L + 2 * L + b * K * 2 * L) * W
+    per_mul = (2 * (L * L + 22 * L + 7) + (4 * L + 4 * M) + (4 * M + 3 * M) + (3 * M + 3 * L) + (3 * L * L + 2 * L)) * W
+    stage_c = b * 5 * L * W
+    return stage_a + b * (K - 1) * per_mul + stage_c
+
+
 def pmc_traffic(config):
     """HBM bytes per NTT launch from the committed rocprofv3 PMC passes of this same command
     (profiles/latest_pmc.json, written by tools/pmc_summary.py; FETCH_SIZE x2 + WRITE_SIZE, gfx950
@@ -180,6 +203,7 @@ def main():
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the multi-core leg of the CPU baseline")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end PSI wall-clock leg")
     ap.add_argument("--streams", type=int, default=0,
@@ -344,14 +368,21 @@ def main():
                                       b_local, b_local * K * E, b_local * (K - 1), b_local),
                        "result_ciphertexts_per_step": b_total, "parallelism": "bins%d" % world,
                        "collective": "rccl all_gather of results" if use_dist else "none"},
-            "mac_per_s": b_total * K * E / (ms_per_step * 1e-3), "run_streams": args.streams if args.streams else 2,
+            "mac_per_s": b_total * K * E / (ms_per_step * 1e-3), "mul_per_s": b_total * (K - 1) / (ms_per_step * 1e-3),
+            "run_streams": args.streams if args.streams else 2,
+            # whole run(): algorithmic bytes of the reference's unfused schedule over the measured time
+            "run_roofline": {"alg_bytes_per_run_per_gpu": alg_bytes_run(dict(cfg, b=b_local)),
+                             "achieved_GBps_per_gpu": alg_bytes_run(dict(cfg, b=b_local)) / (ms_per_step * 1e-3) / 1e9,
+                             "frac": alg_bytes_run(dict(cfg, b=b_local)) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "roofline": roofline, "kernels": kernels,
         }
         if not args.no_e2e and world == 1:
             line["e2e_psi"] = e2e_psi(cfg, pie, cc, lambda: torch.cuda.synchronize(device))
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(cfg)
+            line["cpu_baseline"] = cpu_baseline(cfg, max_threads=max(1, args.cpu_threads))
             line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]
+            if "all_cores" in line["cpu_baseline"]:
+                line["speedup_vs_cpu_all_cores"] = value / line["cpu_baseline"]["all_cores"]["value"]
             if "e2e_psi" in line:
                 line["e2e_speedup_vs_cpu_1core"] = line["cpu_baseline"]["e2e_psi_cpu_s"]["total_s"] / line["e2e_psi"]["total_s"]
         sys.stdout.flush()
