@@ -7,7 +7,7 @@ LIB_PATH = os.path.join(HERE, "libpiehip.so")
 
 
 def build(force=False):
-    args = ["make", "-C", os.path.join(HERE, "csrc")]
+    args = ["make", "-j%d" % min(8, os.cpu_count() or 1), "-C", os.path.join(HERE, "csrc")]
     if force:
         args.append("-B")
     subprocess.check_call(args)
