@@ -208,6 +208,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end PSI wall-clock leg")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams run() spreads the bin layers over (0 = library default, 1 = serial: every kernel alone on the GPU)")
+    ap.add_argument("--collective", default="gather", choices=["gather", "all_gather"],
+                    help="result collection across ranks: to rank 0 (what a server needs) or to every rank")
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: run the RCCL gather path even with one rank (launch under torch.distributed.run)")
     args = ap.parse_args()
@@ -276,6 +278,7 @@ def main():
         bmax = shard.max_bins(b, world) if args.scaling == "strong" else b_local
         my_out = [torch.zeros((bmax, ct_words), dtype=torch.int64, device=device) for _ in range(2)]
         gathered = [torch.empty((world * bmax, ct_words), dtype=torch.int64, device=device) for _ in range(2)]
+        gather_lists = [list(g.view(world, bmax, ct_words).unbind(0)) for g in gathered]
         works = [None, None]
     state = {"i": 0}
 
@@ -293,8 +296,12 @@ def main():
                 # results go straight into the gather buffer; the kernel that writes them waits for the line above
                 op.run(sync=False, into=my_out[s_].data_ptr())
                 op.join()                                     # this stream (and the gather behind it) waits for the run
-            # the path's only collective: RCCL all-gather of the result ciphertexts
-            works[s_] = dist.all_gather_into_tensor(gathered[s_], my_out[s_], async_op=True)
+            # the path's only collective: the result ciphertexts go to rank 0 over each rank's own xGMI link
+            # (--collective all_gather replicates them on every rank: 8x the bytes)
+            if args.collective == "gather":
+                works[s_] = dist.gather(my_out[s_], gather_list=gather_lists[s_] if rank == 0 else None, dst=0, async_op=True)
+            else:
+                works[s_] = dist.all_gather_into_tensor(gathered[s_], my_out[s_], async_op=True)
 
     def drain():
         if use_dist:
@@ -367,7 +374,7 @@ def main():
                                    % (args.config, N, L, t, cfg["S"].bit_length() - 1, cfg["C"].bit_length() - 1, cfg["k"], cfg["e"], B, K, E,
                                       b_local, b_local * K * E, b_local * (K - 1), b_local),
                        "result_ciphertexts_per_step": b_total, "parallelism": "bins%d" % world,
-                       "collective": "rccl all_gather of results" if use_dist else "none"},
+                       "collective": ("rccl %s of results" % args.collective) if use_dist else "none"},
             "mac_per_s": b_total * K * E / (ms_per_step * 1e-3), "mul_per_s": b_total * (K - 1) / (ms_per_step * 1e-3),
             "run_streams": args.streams if args.streams else 2,
             # whole run(): algorithmic bytes of the reference's unfused schedule over the measured time

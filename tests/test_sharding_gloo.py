@@ -43,6 +43,19 @@ def _worker(rank, world, port, b, q):
         full = shard.gather_bins(local_t, b, world)
         want = o.pie_run(idx, minus, db, masks, evk).reshape(b, 2 * L * N).view(np.int64)
         ok = bool((full.numpy() == want).all()) and full.shape[0] == b
+        # the server's form: results to rank 0 only, asynchronously (what bench.py does over RCCL)
+        out0, work = shard.gather_bins_to(local_t, b, world, dst=0, async_op=True)
+        if work is not None:
+            work.wait()
+        if rank == 0:
+            bmax = shard.max_bins(b, world)
+            rows = []
+            for r in range(world):
+                rlo, rhi = shard.bin_slice(b, r, world)
+                rows.append(out0[r * bmax: r * bmax + (rhi - rlo)])
+            ok = ok and bool((torch.cat(rows).numpy() == want).all())
+        else:
+            ok = ok and out0 is None
         q.put((rank, ok, (lo, hi)))
     except Exception as e:  # report instead of hanging the parent on q.get
         q.put((rank, False, repr(e)))
