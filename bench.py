@@ -299,8 +299,12 @@ def main():
             # the path's only collective: the result ciphertexts go to rank 0 over each rank's own xGMI link
             # (--collective all_gather replicates them on every rank: 8x the bytes)
             if args.collective == "gather":
-                works[s_] = dist.gather(my_out[s_], gather_list=gather_lists[s_] if rank == 0 else None, dst=0, async_op=True)
-            else:
+                try:
+                    works[s_] = dist.gather(my_out[s_], gather_list=gather_lists[s_] if rank == 0 else None, dst=0, async_op=True)
+                except (RuntimeError, NotImplementedError) as exc:  # a backend without gather: every rank lands here alike
+                    sys.stderr.write("gather unavailable (%s); using all_gather\n" % exc)
+                    args.collective = "all_gather"
+            if args.collective == "all_gather":
                 works[s_] = dist.all_gather_into_tensor(gathered[s_], my_out[s_], async_op=True)
 
     def drain():
