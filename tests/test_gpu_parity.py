@@ -533,3 +533,23 @@ def test_caller_supplied_moduli(ob, pie, N, L, t, below, what):
     op.run()
     assert (op.getResultList() == o.pie_run(idx, minus, db, masks, evk)).all()
     cc.close()
+
+
+@pytest.mark.parametrize("E,b", [(1, 1), (1, 3), (15, 2), (16, 3), (40, 5)])
+def test_run_shape_extremes(ob, pie, E, b):
+    """one inner position, the last E of the carry-free accumulator (15), the first E of the 128-bit accumulator (16), a long
+    reduction (40), odd bin-layer counts across the two queues -- random limbs, ciphertext bits vs the oracle"""
+    N, L, t, K = 2048, 3, T32, 2
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(1000 * E + b)
+    q = o.moduli[:L]
+    idx, minus = rand_limbs(rng, q, (K, E, 2), N), rand_limbs(rng, q, (2,), N)
+    db, masks, evk = rand_limbs(rng, q, (K, b, E), N), rand_limbs(rng, q, (b,), N), rand_limbs(rng, q, (L, 2), N)
+    cc.load_relin_key(evk)
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    op.setMinusCompareElement(minus)
+    op.setIndex(idx)
+    op.run()
+    assert (op.getResultList() == o.pie_run(idx, minus, db, masks, evk)).all()
+    cc.close()
