@@ -85,3 +85,14 @@ def test_tabulation_hash_matches_oracle(built, ob):
         for hf in range(4):
             got = pie.tabulation_hash(seed, 4, hf, x)
             assert [int(v) for v in got] == [tab.hash(int(v), hf) for v in x]
+
+
+def test_bench_algorithmic_bytes_follow_the_survey():
+    """one run() of the reference schedule moves 253 + 14 * 54 + 35 = 1044 MiB at C3 (unfused limb passes)"""
+    import bench
+    cfg = bench.CONFIGS["C3"]
+    assert bench.alg_bytes_run(cfg) == 1044 * 2**20
+    N, L, K, E, b = cfg["N"], cfg["L"], cfg["K"], cfg["E"], cfg["b"]
+    W = 8 * N
+    assert (b * K * E * L + K * E * 2 * L + 2 * L + b * K * 2 * L) * W == 253 * 2**20      # stage A
+    assert bench.alg_bytes_run(dict(cfg, b=1)) - bench.alg_bytes_run(dict(cfg, b=0)) > 54 * 2**20
