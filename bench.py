@@ -208,8 +208,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end PSI wall-clock leg")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams run() spreads the bin layers over (0 = library default, 1 = serial: every kernel alone on the GPU)")
-    ap.add_argument("--collective", default="gather", choices=["gather", "all_gather"],
-                    help="result collection across ranks: to rank 0 (what a server needs) or to every rank")
+    ap.add_argument("--collective", default="auto", choices=["auto", "gather", "all_gather"],
+                    help="result collection across ranks: to rank 0 (what a server needs) or to every rank; auto times both "
+                         "once before the warm-up and keeps the faster")
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: run the RCCL gather path even with one rank (launch under torch.distributed.run)")
     args = ap.parse_args()
@@ -282,6 +283,36 @@ def main():
         works = [None, None]
     state = {"i": 0}
 
+    def launch_collective(kind, s_):
+        if kind == "gather":
+            return dist.gather(my_out[s_], gather_list=gather_lists[s_] if rank == 0 else None, dst=0, async_op=True)
+        return dist.all_gather_into_tensor(gathered[s_], my_out[s_], async_op=True)
+
+    if use_dist and args.collective == "auto":
+        # both move the same payload; which one RCCL runs faster over this node's xGMI topology is measured, not assumed
+        times = {}
+        for kind in ("gather", "all_gather"):
+            try:
+                for rep in range(6):
+                    if rep == 1:
+                        torch.cuda.synchronize(device)
+                        dist.barrier()
+                        t_ = time.perf_counter()
+                    launch_collective(kind, rep & 1).wait()
+                torch.cuda.synchronize(device)
+                tt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=device)
+                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                times[kind] = float(tt_.item())
+            except (RuntimeError, NotImplementedError) as exc:   # every rank fails alike
+                sys.stderr.write("%s unavailable: %s\n" % (kind, exc))
+        # the gather moves 1/world of the all-gather's bytes (less interference with run()): keep it unless clearly slower
+        if "gather" in times and ("all_gather" not in times or times["gather"] <= 1.15 * times["all_gather"]):
+            args.collective = "gather"
+        else:
+            args.collective = "all_gather"
+        if rank == 0:
+            sys.stderr.write("collective timing (5 rounds, s): %s -> %s\n" % (times, args.collective))
+
     def step():
         if not use_dist:
             if op is not None:
@@ -298,14 +329,7 @@ def main():
                 op.join()                                     # this stream (and the gather behind it) waits for the run
             # the path's only collective: the result ciphertexts go to rank 0 over each rank's own xGMI link
             # (--collective all_gather replicates them on every rank: 8x the bytes)
-            if args.collective == "gather":
-                try:
-                    works[s_] = dist.gather(my_out[s_], gather_list=gather_lists[s_] if rank == 0 else None, dst=0, async_op=True)
-                except (RuntimeError, NotImplementedError) as exc:  # a backend without gather: every rank lands here alike
-                    sys.stderr.write("gather unavailable (%s); using all_gather\n" % exc)
-                    args.collective = "all_gather"
-            if args.collective == "all_gather":
-                works[s_] = dist.all_gather_into_tensor(gathered[s_], my_out[s_], async_op=True)
+            works[s_] = launch_collective(args.collective, s_)
 
     def drain():
         if use_dist:
