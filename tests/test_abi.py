@@ -96,3 +96,11 @@ def test_bench_algorithmic_bytes_follow_the_survey():
     W = 8 * N
     assert (b * K * E * L + K * E * 2 * L + 2 * L + b * K * 2 * L) * W == 253 * 2**20      # stage A
     assert bench.alg_bytes_run(dict(cfg, b=1)) - bench.alg_bytes_run(dict(cfg, b=0)) > 54 * 2**20
+
+
+def test_wire_framing_round_trip(tmp_path):
+    """host/WireFraming.hpp: the reference channel's size-prefixed messages and empty phase-barrier message
+    (BatchedFHEPSIServer.cpp:26,118,134,150; PSIServer.hpp:46-49) over a socket pair, online-phase message order"""
+    exe = str(tmp_path / "wire_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "wire_check.cpp")])
+    assert subprocess.call([exe]) == 0
