@@ -101,6 +101,7 @@ def test_bench_algorithmic_bytes_follow_the_survey():
 def test_wire_framing_round_trip(tmp_path):
     """host/WireFraming.hpp: the reference channel's size-prefixed messages and empty phase-barrier message
     (BatchedFHEPSIServer.cpp:26,118,134,150; PSIServer.hpp:46-49) over a socket pair, online-phase message order"""
+    import subprocess
     exe = str(tmp_path / "wire_check")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "wire_check.cpp")])
     assert subprocess.call([exe]) == 0
