@@ -1,0 +1,116 @@
+// BatchedFHEPSIServer.hpp -- the caller of the hot path, in the reference's shape, over the C ABI and WireFraming.hpp.
+//
+// Mirrors src/Server/FHE/BatchedFHEPSIServer.{hpp,cpp} and the phase driver src/Server/PSIServer.hpp:66-87:
+//     run():  runSetUpPhase(); signalPhaseOver(); runOfflinePhase(); signalPhaseOver(); runOnlinePhase();
+//     setup   (.cpp:56-74)   three messages: context, public key (unused by the operator), EvalMult key
+//     offline (.cpp:75-90)   insertAll(serverSet) + BatchedFHEHIPPIE construction  -> piehip_build_db (all on the device)
+//     online  (.cpp:92-112)  minus ciphertext, K*E index ciphertexts (one message each, .cpp:124-141); timer around
+//                            setMinusCompareElement / setIndex / run (.cpp:98-106); b results, one message each (.cpp:143-152)
+// Payloads are the flat limb format of WireFraming.hpp instead of OpenFHE's cereal blobs (OpenFHE is not available here);
+// with OpenFHE the same class deserialises the blobs and copies DCRTPoly towers.
+#pragma once
+#include <chrono>
+#include <memory>
+
+#include "BatchedFHEHIPPIE.hpp"
+#include "WireFraming.hpp"
+
+namespace piehip {
+
+struct HashTableParameter {  // src/Common/Parameter/HashTableParameter.hpp
+    uint32_t numberOfSimpleHashFunctions, eachSimpleTableSize, numberOfCuckooHashFunctions, eachCuckooTableSize, maxItemsPerPosition;
+    uint64_t serverStashSize = 0;
+};
+
+// first setup message: what the reference's serialized CryptoContext carries for this path
+struct ContextMessage {
+    uint32_t N, L;
+    uint64_t t;
+    uint64_t moduli[2 * 7 + 1];  // q_0..q_{L-1}, p_0..p_L
+};
+
+class BatchedFHEPSIServer {
+public:
+    BatchedFHEPSIServer(int channel_fd, const std::vector<uint64_t> &serverSet, const HashTableParameter &htParams, uint64_t hashSeed = 987654321)
+        : fd(channel_fd), serverSet(serverSet), ht(htParams), hashSeed(hashSeed)
+    {
+        if (ht.serverStashSize != 0) throw std::invalid_argument("Error, batched FHE PIE does not support a stash (yet).");
+    }
+
+    void run()  // PSIServer.hpp:66-87
+    {
+        runSetUpPhase();
+        wire::signalPhaseOver(fd);
+        runOfflinePhase();
+        wire::signalPhaseOver(fd);
+        runOnlinePhase();
+    }
+
+    long long offlineComputation = 0, onlineComputation = 0;  // microseconds, PSIServer.hpp:89-103
+
+    void runSetUpPhase()  // receiveAndSetContextAndKeys, BatchedFHEPSIServer.cpp:21-54
+    {
+        std::vector<uint8_t> m;
+        wire::readWithSizeIntoVector(fd, m);
+        if (m.size() != sizeof(ContextMessage)) throw std::runtime_error("context message size");
+        ContextMessage c;
+        std::memcpy(&c, m.data(), sizeof(c));
+        if (c.L < 1 || c.L > 7) throw std::invalid_argument("context: L out of range");
+        cc.reset(new PieContext(c.N, c.L, c.t, c.moduli, c.moduli + c.L));
+        wire::readWithSizeIntoVector(fd, m);  // public key: stored by the reference, never used by the operator
+        wire::readWithSizeIntoVector(fd, m);  // EvalMult key [L][2][L][N]
+        const size_t words = (size_t)c.L * 2 * c.L * c.N;
+        if (m.size() != words * sizeof(uint64_t)) throw std::runtime_error("EvalMult key message size");
+        std::vector<uint64_t> evk(words);
+        std::memcpy(evk.data(), m.data(), m.size());
+        cc->setEvalMultKey(evk.data());
+    }
+
+    void runOfflinePhase()  // BatchedFHEPSIServer.cpp:75-90
+    {
+        const auto begin = std::chrono::steady_clock::now();
+        // nested hashing (HierarchicalCuckooHashTable::insertAll) + the operator's constructor, on the device
+        PieContext::check(piehip_build_db(cc->handle(), serverSet.data(), serverSet.size(), ht.numberOfSimpleHashFunctions,
+                                          ht.eachSimpleTableSize, ht.numberOfCuckooHashFunctions, ht.maxItemsPerPosition,
+                                          ht.eachCuckooTableSize, hashSeed, 1, 2, 3));
+        PieContext::check(piehip_sync(cc->handle()));
+        offlineComputation = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - begin).count();
+    }
+
+    void runOnlinePhase()  // BatchedFHEPSIServer.cpp:92-112
+    {
+        const uint32_t L = cc->towers(), N = cc->ringDimension(), K = ht.numberOfCuckooHashFunctions, E = ht.eachCuckooTableSize,
+                       b = ht.maxItemsPerPosition;
+        const size_t ct = 2 * (size_t)L * N;
+        std::vector<uint8_t> m;
+        std::vector<uint64_t> minus, one, idx;
+        wire::readWithSizeIntoVector(fd, m);  // receiveEncryptedMinusElements, .cpp:114-122
+        if (wire::unpackCiphertexts(m, L, N, minus) != 1) throw std::runtime_error("minus element: one ciphertext expected");
+        idx.reserve((size_t)K * E * ct);
+        for (uint32_t i = 0; i < K * E; i++) {  // receiveIndexMatrix, .cpp:124-141
+            wire::readWithSizeIntoVector(fd, m);
+            if (wire::unpackCiphertexts(m, L, N, one) != 1) throw std::runtime_error("index matrix: one ciphertext per message expected");
+            idx.insert(idx.end(), one.begin(), one.end());
+        }
+        const auto begin = std::chrono::steady_clock::now();
+        PieContext::check(piehip_set_minus(cc->handle(), minus.data()));
+        PieContext::check(piehip_set_index(cc->handle(), idx.data()));
+        PieContext::check(piehip_run(cc->handle()));
+        std::vector<uint64_t> res((size_t)b * ct);
+        PieContext::check(piehip_get_results(cc->handle(), res.data()));
+        onlineComputation = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - begin).count();
+        for (uint32_t i = 0; i < b; i++) {  // sendResult, .cpp:143-152
+            const auto out = wire::packCiphertexts(&res[(size_t)i * ct], 1, L, N);
+            wire::writeWithSize(fd, out.data(), out.size());
+        }
+    }
+
+private:
+    int fd;
+    std::vector<uint64_t> serverSet;
+    HashTableParameter ht;
+    uint64_t hashSeed;
+    std::unique_ptr<PieContext> cc;
+};
+
+}  // namespace piehip

@@ -105,3 +105,14 @@ def test_wire_framing_round_trip(tmp_path):
     exe = str(tmp_path / "wire_check")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "wire_check.cpp")])
     assert subprocess.call([exe]) == 0
+
+
+def test_cpp_server_harness_compiles(built, tmp_path):
+    """host/BatchedFHEPSIServer.hpp (the caller of the hot path, reference phase order) builds warning-free against the C ABI;
+    it runs in tests/test_gpu_parity.py::test_two_process_psi_over_the_wire"""
+    import subprocess
+    libdir = os.path.join(ROOT, "nested_hashing_psi_amd")
+    exe = str(tmp_path / "server_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "server_main.cpp"),
+                           "-L" + libdir, "-lpiehip", "-Wl,-rpath," + libdir])
+    assert subprocess.call([exe]) == 2  # usage error: no arguments
