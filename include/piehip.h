@@ -221,8 +221,9 @@ enum {
     PIEHIP_K_OTHER = 11
 };
 /* times `iters` back-to-back NTT launches over nlimbs random limbs (moduli cycle over mod_count from 0);
- * returns the average milliseconds per launch.  Used by bench tooling to sweep batch sizes. */
-int piehip_bench_ntt(piehip_handle h, uint32_t nlimbs, uint32_t mod_count, int inverse, uint32_t iters, double *ms_per_launch);
+ * flags: bit 0 = inverse transform, bit 1 = EVALUATION side in the library's internal lane order.
+ * Returns the average milliseconds per launch.  Used by bench tooling to sweep batch sizes. */
+int piehip_bench_ntt(piehip_handle h, uint32_t nlimbs, uint32_t mod_count, int flags, uint32_t iters, double *ms_per_launch);
 int piehip_set_profiling(piehip_handle h, int on);
 int piehip_profile_read(piehip_handle h, uint32_t *launches /*[NKERNELS]*/, double *ms /*[NKERNELS]*/,
                         double *alg_bytes /*[NKERNELS]*/);

@@ -3,11 +3,25 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <vector>
 
 #include "params.hpp"
 
 namespace piehip {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one bit per device ordinal and kernel instantiation,
+// so that handles on several devices of one process each raise the limit where they launch.
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    bool first_on_current_device()
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+        const unsigned long long bit = 1ULL << dev;
+        return (done.fetch_or(bit) & bit) == 0;
+    }
+};
 
 // Device-resident NTT tables: for modulus a, tables + a*4*N holds tw | tw_sh | itw | itw_sh (N each).
 struct NttPlan {

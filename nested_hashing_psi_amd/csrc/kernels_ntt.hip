@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) ntt_global_stage(NttArgs a, u32 mstage, u
     }
 }
 
-static bool g_attr_set[2] = {false, false};
+static PerDeviceOnce g_attr_set[2];
 
 u32 ntt_fast_s0(u32 logN)
 {
@@ -180,7 +180,7 @@ void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_
     u32 threads = nl / 2;
     if (threads > 1024) threads = 1024;
     if (threads < 64) threads = 64;
-    if (!g_attr_set[inverse ? 1 : 0]) {
+    if (g_attr_set[inverse ? 1 : 0].first_on_current_device()) {
         // a workgroup may use up to 160 KiB of LDS on gfx950; raise the dynamic-LDS cap once
         if (inverse)
             (void)hipFuncSetAttribute((const void *)ntt_lds_generic<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -188,7 +188,6 @@ void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_
         else
             (void)hipFuncSetAttribute((const void *)ntt_lds_generic<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (1 << NTT_LDS_MAX_LOG) * 8);
-        g_attr_set[inverse ? 1 : 0] = true;
     }
     const dim3 ggrid((pl.N / 2 + 255) / 256, nlimbs);
     const bool fast_ok = !pl.force_generic && pl.twp && pl.twc && pl.logN - a.s0 >= 12;

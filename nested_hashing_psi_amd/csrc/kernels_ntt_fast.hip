@@ -91,37 +91,6 @@ __device__ __forceinline__ u64 shoup4(u64 b, u64 w, u64 ws, u64 nq)
     return acc + ((u64)(u32)c << 32);
 }
 
-// two independent products with the dependent mad chains interleaved statement by statement: hipcc keeps
-// source order for the asm statements, and back-to-back dependent v_mad_u64_u32 leave the multiplier idle
-__device__ __forceinline__ void shoup4x2(u64 b0, u64 w0, u64 s0, u64 b1, u64 w1, u64 s1, u64 nq, u64 &r0, u64 &r1)
-{
-    const u32 b0l = (u32)b0, b0h = (u32)(b0 >> 32), w0l = (u32)w0, w0h = (u32)(w0 >> 32), s0l = (u32)s0, s0h = (u32)(s0 >> 32);
-    const u32 b1l = (u32)b1, b1h = (u32)(b1 >> 32), w1l = (u32)w1, w1h = (u32)(w1 >> 32), s1l = (u32)s1, s1h = (u32)(s1 >> 32);
-    const u32 nql = (u32)nq, nqh = (u32)(nq >> 32);
-    const u64 m0 = mul_u(b0l, s0h);
-    const u64 m1 = mul_u(b1l, s1h);
-    const u64 t0 = mul_u(b0h, s0h);
-    const u64 t1 = mul_u(b1h, s1h);
-    const u64 c0 = mad_u(b0h, s0l, m0);
-    const u64 c1 = mad_u(b1h, s1l, m1);
-    const u64 q0 = (t0 << 1) + (c0 >> 31);
-    const u64 q1 = (t1 << 1) + (c1 >> 31);
-    u64 a0 = mul_u((u32)q0, nql);
-    u64 a1 = mul_u((u32)q1, nql);
-    u64 x0 = mul_u((u32)q0, nqh);
-    u64 x1 = mul_u((u32)q1, nqh);
-    a0 = mad_u(b0l, w0l, a0);
-    a1 = mad_u(b1l, w1l, a1);
-    x0 = mad_u((u32)(q0 >> 32), nql, x0);
-    x1 = mad_u((u32)(q1 >> 32), nql, x1);
-    x0 = mad_u(b0l, w0h, x0);
-    x1 = mad_u(b1l, w1h, x1);
-    x0 = mad_u(b0h, w0l, x0);
-    x1 = mad_u(b1h, w1l, x1);
-    r0 = a0 + ((u64)(u32)x0 << 32);
-    r1 = a1 + ((u64)(u32)x1 << 32);
-}
-
 // Harvey butterflies on lazy residues ------------------------------------------------------------------------
 // forward: inputs in [0, 8q), outputs in [0, 8q)
 __device__ __forceinline__ void ct_bfly(u64 &a, u64 &b, u64 w, u64 ws, u64 nq, u64 q4)
@@ -139,61 +108,21 @@ __device__ __forceinline__ void gs_bfly(u64 &a, u64 &b, u64 w, u64 ws, u64 nq, u
     a = s >= q4 ? s - q4 : s;
     b = shoup4(d, w, ws, nq);
 }
-// (two-at-a-time variants: measured no faster forward and spill in the 2^14 inverse; kept for experiments)
-// forward: inputs in [0, 8q), outputs in [0, 8q)
-__device__ __forceinline__ void ct_bfly2(u64 &a0, u64 &b0, u64 &a1, u64 &b1, u64x2 w0, u64x2 w1, u64 nq, u64 q4)
-{
-    u64 v0, v1;
-    shoup4x2(b0, w0.x, w0.y, b1, w1.x, w1.y, nq, v0, v1);
-    const u64 u0 = a0 >= q4 ? a0 - q4 : a0;
-    const u64 u1 = a1 >= q4 ? a1 - q4 : a1;
-    a0 = u0 + v0;
-    a1 = u1 + v1;
-    b0 = u0 - v0 + q4;
-    b1 = u1 - v1 + q4;
-}
-// inverse: inputs in [0, 4q), outputs in [0, 4q)
-__device__ __forceinline__ void gs_bfly2(u64 &a0, u64 &b0, u64 &a1, u64 &b1, u64x2 w0, u64x2 w1, u64 nq, u64 q4)
-{
-    const u64 s0 = a0 + b0, s1 = a1 + b1;
-    const u64 d0 = a0 - b0 + q4, d1 = a1 - b1 + q4;
-    a0 = s0 >= q4 ? s0 - q4 : s0;
-    a1 = s1 >= q4 ? s1 - q4 : s1;
-    shoup4x2(d0, w0.x, w0.y, d1, w1.x, w1.y, nq, b0, b1);
-}
-
 // m-th index in [0,32) whose bit `d` (a power of two) is clear
 __device__ __forceinline__ constexpr int bfly_lo(int m, int d) { return ((m & ~(d - 1)) << 1) | (m & (d - 1)); }
 
 // LDS hand-off inside one wave: DS operations of a wave execute in issue order, so only the compiler has to
 // be kept from moving the reads above the writes
-#ifdef NTT_DBG_FULLSYNC
-#define WAVE_LOCAL_SYNC() __syncthreads()
-#else
 #define WAVE_LOCAL_SYNC()                                   \
     do {                                                    \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
         __builtin_amdgcn_wave_barrier();                    \
     } while (0)
-#endif
 
 // keeps hipcc from interleaving more than a few butterflies (each carries ~12 VGPRs of temporaries)
-#ifndef FENCE_EVERY
 #define FENCE_EVERY 16
-#endif
-#ifdef NTT_STAMPS
-#define STAMP(i)                                                                                   \
-    do {                                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (blockIdx.x == 0 && iter == 1) {                                                        \
-            unsigned long long t_;                                                                 \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
-            if (threadIdx.x == 0) gdata[(size_t)a.nitems * n + (i)] = t_;                          \
-            if (threadIdx.x == 448) gdata[(size_t)a.nitems * n + 32 + (i)] = t_;                    \
-        }                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-    } while (0)
-#else
+// in-kernel cycle stamps are a tooling build (tools/ntt_stamps.hip defines STAMP before including this file)
+#ifndef STAMP
 #define STAMP(i)
 #endif
 #define BFLY_FENCE(cnt, every)                                         \
@@ -223,13 +152,7 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
     constexpr u32 SB = NB / 32;     // pass-B stride
     constexpr int C = LOGN - 9;     // pass-C stages
     extern __shared__ __attribute__((aligned(16))) u64 lds_real[];
-#ifdef NTT_EXP_NOLDS
-    u64 *lds = lds_real + (threadIdx.x == 4096 ? 1 : 0);  // defeat alias analysis cheaply
-#define LDS_ON (threadIdx.x == 4097)
-#else
     u64 *lds = lds_real;
-#define LDS_ON true
-#endif
 
     const u32 tau = threadIdx.x;
     const u32 beta = tau / SB, rho = tau % SB;
@@ -293,18 +216,8 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
         // order would touch 64 cache lines per wave instruction in the last stage)
         constexpr u32 JT = 32 - (32 >> C);  // twiddles per thread over the C stages
         const u64x2 *__restrict__ twc = gtwc + (((size_t)mod * 2 + (INV ? 1 : 0)) * (1u << a.s0) + blk) * (T * JT) + tau;
-#ifdef NTT_EXP_NOTW
-        const u64x2 wconst = tw[1];
-#define TWL(idx) wconst
-#define TWC(sc, j) wconst
-#else
 #define TWL(idx) tw[idx]
-#ifdef NTT_DBG_NATTW
-#define TWC(sc, j) tw[((512u << (sc)) << a.s0) + blk * (512u << (sc)) + (tau << (5 - C + (sc))) + (j)]
-#else
 #define TWC(sc, j) twc[T * ((32u >> C) * ((1u << (sc)) - 1) + (j))]
-#endif
-#endif
         u64 *g = gdata + slice * n;
 
         STAMP(1);
@@ -327,11 +240,7 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
                     // pass A needs no vector loads (scalar twiddles), and the data is home before pass B's twiddle
                     // loads queue up behind it.
                     __builtin_amdgcn_sched_barrier(0);
-#ifdef NTT_EXP_NOLOAD
-                    if (next < a.nitems && tau == 1000) {
-#else
                     if (next < a.nitems) {
-#endif
                         const u64 *gn = a.lift_L ? a.lift_src + (size_t)(next / a.lift_L) * n : gdata + slice_of(next) * n;
 #pragma unroll
                         for (int k = 0; k < 16; k++) {
@@ -432,13 +341,9 @@ ntt_fast_kernel(u64 *__restrict__ gdata, const u64x2 *__restrict__ gtw, const u6
             __syncthreads();
             STAMP(12);
             // ---- coalesced copy-out -------------------------------------------------------------------
-#ifndef NTT_EXP_NOSTORE
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 *reinterpret_cast<u64x2 *>(g + 2 * tau + NB * k) = *reinterpret_cast<const u64x2 *>(&lds[phi(2 * tau + NB * k)]);
-#else
-            if (tau == 1000) g[0] = lds[phi(tau)];
-#endif
             STAMP(13);
             STAMP(14);
         } else {
@@ -569,11 +474,9 @@ static void launch_one(const NttFastArgs &a, u32 max_groups, hipStream_t st)
 {
     constexpr u32 n = 1u << LOGN;
     constexpr size_t lds = (size_t)(n + n / 16) * sizeof(u64);
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first_on_current_device())
         (void)hipFuncSetAttribute((const void *)ntt_fast_kernel<LOGN, INV, SIGMA, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
     u32 grid = a.nitems < max_groups ? a.nitems : max_groups;
     hipLaunchKernelGGL((ntt_fast_kernel<LOGN, INV, SIGMA, LAZY>), dim3(grid), dim3(n / 32), lds, st, a.data, reinterpret_cast<const u64x2 *>(a.twp), reinterpret_cast<const u64x2 *>(a.twc), a.dc, a);
 }

@@ -25,7 +25,8 @@ void set_small_moduli(bool v) { g_small_moduli = v; }
 // A thread owns two adjacent coefficients (16-byte lanes) of one (h, limb) and BPT bin layers: the two index
 // ciphertext components are loaded once per j and reused for all BPT layers, so index traffic is
 // (b / BPT) K E 2L W instead of b K E 2L W; the BPT database loads per j are independent streams in flight.
-// 128-bit lazy accumulation (products < 2^120, E < 128 terms), one Barrett reduction at the end.
+// 128-bit lazy accumulation: moduli may be up to 61 bits (HostParams::init), so products are < 2^122 and the
+// accumulator is reduced every 32 terms (2^61 + 32 * 2^122 < 2^128); one more Barrett reduction at the end.
 // ---------------------------------------------------------------------------------------------
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
@@ -62,7 +63,7 @@ __global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *__restric
             mac128(a[t][1][0], i1.x, d[t].x);
             mac128(a[t][1][1], i1.y, d[t].y);
         }
-        if ((j & 127) == 127) {
+        if ((j & 31) == 31) {
 #pragma unroll
             for (int t = 0; t < BPT; t++)
 #pragma unroll

@@ -378,12 +378,9 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
         h->own_stream = true;
     }
     {
-        const char *es = getenv("PIEHIP_STREAMS");  // experiments: PIEHIP_STREAMS=n, 1 keeps run() on one stream
-        int ns = es ? atoi(es) : 2;
-        if (ns < 1) ns = 1;
-        if (ns > 16) ns = 16;
-        if (ns > 1) CHK_(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        for (int i = 0; i < ns && ns > 1; i++) {
+        const int ns = 2;  // queues of run(): see piehip_run_into (3 is equal within noise, 4 and more collapse)
+        CHK_(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < ns; i++) {
             hipStream_t s = nullptr;
             hipEvent_t e = nullptr;
             CHK_(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -565,7 +562,9 @@ int piehip_load_relin_key(piehip_handle h, const uint64_t *evk)
         int rc = dev_alloc(&h->d_evk, words);
         if (rc) return rc;
     }
-    HIPCHK(hipMemcpy(h->d_evk, evk, words * sizeof(u64), hipMemcpyHostToDevice));
+    // on the handle's stream: NEED() has ordered it behind every run still in flight (a null-stream copy would not be)
+    HIPCHK(hipMemcpyAsync(h->d_evk, evk, words * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     if (h->sigma_on) {  // lane-ordered copy for the key-switch MAC
         if (!h->d_evk_sigma) {
             int rc = dev_alloc(&h->d_evk_sigma, words);
@@ -633,8 +632,9 @@ int piehip_load_db(piehip_handle h, uint32_t K, uint32_t b, uint32_t E, const ui
     int rc = alloc_run_buffers(h, K, b, E);
     if (rc) return rc;
     const size_t LN = h->LN();
-    HIPCHK(hipMemcpy(h->d_db, pts, sizeof(u64) * (size_t)K * b * E * LN, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_masks, masks, sizeof(u64) * (size_t)b * LN, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(h->d_db, pts, sizeof(u64) * (size_t)K * b * E * LN, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_masks, masks, sizeof(u64) * (size_t)b * LN, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return make_masks_sigma(h);
 }
 
@@ -934,14 +934,13 @@ int piehip_run_into(piehip_handle h, void *d_results)
         } restore{h, h->stream};
         HIPCHK(hipEventRecord(h->ev_fork, restore.s));
         u32 b0 = 0;
-        static const int split0 = [] { const char *e = getenv("PIEHIP_SPLIT"); return e ? atoi(e) : 0; }();  // experiments
         for (u32 g = 0; g < ng; g++) {
             u32 nb = b / ng + (g < b % ng ? 1 : 0);
             if (ng == 2) {
                 // two groups of 4/7 and 3/7 of the layers: measured 3.5 % faster than equal halves at b = 14 (8 + 6: the
                 // ragged transform launches of the two queues fit the 512 workgroup slots better than 7 + 7); a queue
                 // offset of half a chain made no difference
-                const u32 first = (split0 > 0 && (u32)split0 < b) ? (u32)split0 : (4 * b + 3) / 7;
+                const u32 first = (4 * b + 3) / 7;
                 nb = g == 0 ? first : b - first;
             }
             if (h->inputs_dirty) HIPCHK(hipStreamWaitEvent(h->side_streams[g], h->ev_fork, 0));
@@ -956,6 +955,7 @@ int piehip_run_into(piehip_handle h, void *d_results)
     } else {
         join_pending(h);
         enqueue_run_bins(h, 0, b, (u64 *)d_results);
+        mark_dirty(h);  // the workspace is now in use on the handle's stream: the queues of a later multi-queue run wait for it
     }
     HIPCHK(hipGetLastError());
     return PIEHIP_OK;
@@ -1403,7 +1403,7 @@ int piehip_fhepie_get_results(piehip_handle h, uint64_t *out)
     return PIEHIP_OK;
 }
 
-int piehip_bench_ntt(piehip_handle h, uint32_t nlimbs, uint32_t mod_count, int inverse, uint32_t iters, double *ms_per_launch)
+int piehip_bench_ntt(piehip_handle h, uint32_t nlimbs, uint32_t mod_count, int flags, uint32_t iters, double *ms_per_launch)
 {
     NEED(h);
     if (!nlimbs || !mod_count || mod_count > h->hp.M || !iters || !ms_per_launch) return fail(PIEHIP_EINVAL, "bad argument");
@@ -1411,11 +1411,7 @@ int piehip_bench_ntt(piehip_handle h, uint32_t nlimbs, uint32_t mod_count, int i
     Tmp tmp;
     const u32 N = h->hp.N;
     const size_t words = (size_t)nlimbs * N;
-#ifdef NTT_STAMPS
-    TMPGET(d, words + 64);
-#else
     TMPGET(d, words);
-#endif
     {   // residues below the smallest modulus are valid for every limb
         std::vector<u64> host(words);
         u64 lo = h->hp.moduli[0];
@@ -1430,10 +1426,10 @@ int piehip_bench_ntt(piehip_handle h, uint32_t nlimbs, uint32_t mod_count, int i
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    const bool sigma = getenv("PIEHIP_BENCH_SIGMA") != nullptr && h->sigma_on;  // tooling switch: lane-order side
-    launch_ntt(h->plan, d, nlimbs, 0, mod_count, inverse != 0, h->stream, sigma);  // warm-up
+    const bool inverse = (flags & 1) != 0, sigma = (flags & 2) != 0 && h->sigma_on;
+    launch_ntt(h->plan, d, nlimbs, 0, mod_count, inverse, h->stream, sigma);  // warm-up
     HIPCHK(hipEventRecord(e0, h->stream));
-    for (u32 i = 0; i < iters; i++) launch_ntt(h->plan, d, nlimbs, 0, mod_count, inverse != 0, h->stream, sigma);
+    for (u32 i = 0; i < iters; i++) launch_ntt(h->plan, d, nlimbs, 0, mod_count, inverse, h->stream, sigma);
     HIPCHK(hipEventRecord(e1, h->stream));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0;
@@ -1441,17 +1437,6 @@ int piehip_bench_ntt(piehip_handle h, uint32_t nlimbs, uint32_t mod_count, int i
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *ms_per_launch = (double)ms / iters;
-#ifdef NTT_STAMPS
-    {
-        u64 st[64];
-        HIPCHK(hipMemcpy(st, d + words, sizeof(st), hipMemcpyDeviceToHost));
-        for (int w = 0; w < 2; w++) {
-            fprintf(stderr, "stamps wave%d (cycles since iteration start):", w * 7);
-            for (int i = 1; i < 15; i++) fprintf(stderr, " [%d]%lld", i, (long long)(st[32 * w + i] - st[32 * w]));
-            fprintf(stderr, "\n");
-        }
-    }
-#endif
     return PIEHIP_OK;
 }
 

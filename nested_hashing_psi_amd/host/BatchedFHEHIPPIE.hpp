@@ -15,6 +15,7 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -83,13 +84,27 @@ private:
 
 class BatchedFHEHIPPIE {
 public:
+    // Seeds of the bin-layer shuffle (.cpp:23-35) and of the random masks (.cpp:72-82).  The masks are what hides
+    // prod_h (item - x) of a non-matching slot from the client, so they must be secret: the default constructor draws
+    // both seeds from std::random_device as the reference does (.cpp:25-26).  Fixed seeds are for parity tests only.
+    struct Seeds {
+        uint64_t shuffle, mask;
+        static Seeds fromRandomDevice()
+        {
+            std::random_device rd;
+            auto u64 = [&rd] { return ((uint64_t)rd() << 32) ^ (uint64_t)rd(); };
+            return Seeds{u64(), u64()};
+        }
+    };
+
     // BatchedFHEHIPPIE(cryptoContext, pK, hct), BatchedFHEHIPPIE.cpp:9-86.  The public key is unused by the
-    // reference constructor and run() (it is only stored, .hpp:22), so it does not appear here.  The bin-layer
-    // shuffle (.cpp:23-35) and the random masks (.cpp:72-82) take explicit seeds instead of std::random_device.
-    BatchedFHEHIPPIE(PieContext &cryptoContext, const HashTableView &hct, uint64_t shuffleSeed = 0x9E3779B97F4A7C15ULL,
-                     uint64_t maskSeed = 0xD1B54A32D192ED03ULL)
+    // reference constructor and run() (it is only stored, .hpp:22), so it does not appear here.
+    BatchedFHEHIPPIE(PieContext &cryptoContext, const HashTableView &hct) : BatchedFHEHIPPIE(cryptoContext, hct, Seeds::fromRandomDevice()) {}
+    // test-only: reproducible shuffle and masks
+    BatchedFHEHIPPIE(PieContext &cryptoContext, const HashTableView &hct, const Seeds &testSeeds)
         : cc(cryptoContext)
     {
+        const uint64_t shuffleSeed = testSeeds.shuffle, maskSeed = testSeeds.mask;
         if (hct.serverStashSize != 0) throw std::invalid_argument("Error, batched FHE PIE does not support a stash (yet).");
         if (!hct.simpleMultiTables || !hct.cuckooMultiTables)
             throw std::invalid_argument("Error, batched FHE PIE currently does not support combined tables.");
@@ -142,15 +157,6 @@ protected:
     PieContext &cc;
     uint32_t K = 0, b = 0, E = 0;
     std::vector<LimbCt> resultList;
-
-    static uint64_t next(uint64_t &s)  // splitmix64
-    {
-        s += 0x9E3779B97F4A7C15ULL;
-        uint64_t z = s;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-        return z ^ (z >> 31);
-    }
 };
 
 }  // namespace piehip

@@ -11,6 +11,7 @@
 #pragma once
 #include <chrono>
 #include <memory>
+#include <random>
 
 #include "BatchedFHEHIPPIE.hpp"
 #include "WireFraming.hpp"
@@ -31,9 +32,17 @@ struct ContextMessage {
 
 class BatchedFHEPSIServer {
 public:
+    // Cuckoo evictions, the bin-layer shuffle and the random masks are seeded from std::random_device, as in the reference
+    // (CuckooHashTable.cpp:51-52, BatchedFHEHIPPIE.cpp:25-26): the masks hide non-matching slots from the client and the
+    // shuffle hides the bin order.  setSecretSeedsForTesting() makes a run reproducible (parity tests only).
     BatchedFHEPSIServer(int channel_fd, const std::vector<uint64_t> &serverSet, const HashTableParameter &htParams, uint64_t hashSeed = 987654321)
         : fd(channel_fd), serverSet(serverSet), ht(htParams), hashSeed(hashSeed)
     {
+        std::random_device rd;
+        auto u64 = [&rd] { return ((uint64_t)rd() << 32) ^ (uint64_t)rd(); };
+        evictSeed = u64();
+        shuffleSeed = u64();
+        maskSeed = u64();
         if (ht.serverStashSize != 0) throw std::invalid_argument("Error, batched FHE PIE does not support a stash (yet).");
     }
 
@@ -44,6 +53,13 @@ public:
         runOfflinePhase();
         wire::signalPhaseOver(fd);
         runOnlinePhase();
+    }
+
+    void setSecretSeedsForTesting(uint64_t evict, uint64_t shuffle, uint64_t mask)
+    {
+        evictSeed = evict;
+        shuffleSeed = shuffle;
+        maskSeed = mask;
     }
 
     long long offlineComputation = 0, onlineComputation = 0;  // microseconds, PSIServer.hpp:89-103
@@ -57,6 +73,7 @@ public:
         std::memcpy(&c, m.data(), sizeof(c));
         if (c.L < 1 || c.L > 7) throw std::invalid_argument("context: L out of range");
         cc.reset(new PieContext(c.N, c.L, c.t, c.moduli, c.moduli + c.L));
+        qMod.assign(c.moduli, c.moduli + c.L);
         wire::readWithSizeIntoVector(fd, m);  // public key: stored by the reference, never used by the operator
         wire::readWithSizeIntoVector(fd, m);  // EvalMult key [L][2][L][N]
         const size_t words = (size_t)c.L * 2 * c.L * c.N;
@@ -72,7 +89,7 @@ public:
         // nested hashing (HierarchicalCuckooHashTable::insertAll) + the operator's constructor, on the device
         PieContext::check(piehip_build_db(cc->handle(), serverSet.data(), serverSet.size(), ht.numberOfSimpleHashFunctions,
                                           ht.eachSimpleTableSize, ht.numberOfCuckooHashFunctions, ht.maxItemsPerPosition,
-                                          ht.eachCuckooTableSize, hashSeed, 1, 2, 3));
+                                          ht.eachCuckooTableSize, hashSeed, evictSeed, shuffleSeed, maskSeed));
         PieContext::check(piehip_sync(cc->handle()));
         offlineComputation = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - begin).count();
     }
@@ -85,11 +102,11 @@ public:
         std::vector<uint8_t> m;
         std::vector<uint64_t> minus, one, idx;
         wire::readWithSizeIntoVector(fd, m);  // receiveEncryptedMinusElements, .cpp:114-122
-        if (wire::unpackCiphertexts(m, L, N, minus) != 1) throw std::runtime_error("minus element: one ciphertext expected");
+        if (wire::unpackCiphertexts(m, L, N, minus, qMod.data()) != 1) throw std::runtime_error("minus element: one ciphertext expected");
         idx.reserve((size_t)K * E * ct);
         for (uint32_t i = 0; i < K * E; i++) {  // receiveIndexMatrix, .cpp:124-141
             wire::readWithSizeIntoVector(fd, m);
-            if (wire::unpackCiphertexts(m, L, N, one) != 1) throw std::runtime_error("index matrix: one ciphertext per message expected");
+            if (wire::unpackCiphertexts(m, L, N, one, qMod.data()) != 1) throw std::runtime_error("index matrix: one ciphertext per message expected");
             idx.insert(idx.end(), one.begin(), one.end());
         }
         const auto begin = std::chrono::steady_clock::now();
@@ -110,6 +127,8 @@ private:
     std::vector<uint64_t> serverSet;
     HashTableParameter ht;
     uint64_t hashSeed;
+    uint64_t evictSeed = 0, shuffleSeed = 0, maskSeed = 0;
+    std::vector<uint64_t> qMod;
     std::unique_ptr<PieContext> cc;
 };
 

@@ -92,8 +92,11 @@ inline std::vector<uint8_t> packCiphertexts(const uint64_t *limbs, uint32_t coun
     std::memcpy(msg.data() + sizeof(h), limbs, words * sizeof(uint64_t));
     return msg;
 }
-// returns the ciphertext count; throws if the message does not describe [count][2][L][N]
-inline uint32_t unpackCiphertexts(const std::vector<uint8_t> &msg, uint32_t L, uint32_t N, std::vector<uint64_t> &limbs)
+// returns the ciphertext count; throws if the message does not describe [count][2][L][N].  moduli (q_0..q_{L-1}, may be null):
+// every residue of limb i must be canonical, i.e. below q_i -- the device kernels assume it (lazy accumulation), and what
+// arrives here comes from the other party.
+inline uint32_t unpackCiphertexts(const std::vector<uint8_t> &msg, uint32_t L, uint32_t N, std::vector<uint64_t> &limbs,
+                                  const uint64_t *moduli = nullptr)
 {
     if (msg.size() < sizeof(LimbHeader)) throw std::invalid_argument("short ciphertext message");
     LimbHeader h;
@@ -103,6 +106,14 @@ inline uint32_t unpackCiphertexts(const std::vector<uint8_t> &msg, uint32_t L, u
     if (msg.size() != sizeof(LimbHeader) + words * sizeof(uint64_t)) throw std::invalid_argument("ciphertext message length mismatch");
     limbs.resize(words);
     std::memcpy(limbs.data(), msg.data() + sizeof(h), words * sizeof(uint64_t));
+    if (moduli) {
+        for (size_t limb = 0; limb < (size_t)h.count * 2 * L; limb++) {
+            const uint64_t q = moduli[limb % L], *p = &limbs[limb * N];
+            uint64_t bad = 0;
+            for (uint32_t j = 0; j < N; j++) bad |= (uint64_t)(p[j] >= q);
+            if (bad) throw std::invalid_argument("ciphertext residue not below its modulus");
+        }
+    }
     return h.count;
 }
 

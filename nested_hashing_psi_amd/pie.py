@@ -11,6 +11,7 @@ Ciphertexts / plaintexts are numpy uint64 limb arrays in EVALUATION format, the 
 DCRTPoly towers.  Everything executes in libpiehip.so on the GPU; nothing here computes.
 """
 import ctypes as C
+import secrets
 
 import numpy as np
 
@@ -170,9 +171,9 @@ class PieContext:
         _check(lib().piehip_load_rotation_keys(self._h, len(idx), idx.ctypes.data_as(i32p), ka.ctypes.data_as(u64p)))
 
     # -- measurement
-    def bench_ntt(self, nlimbs, mod_count=None, inverse=False, iters=20):
+    def bench_ntt(self, nlimbs, mod_count=None, inverse=False, iters=20, lane_order=False):
         ms = C.c_double()
-        _check(lib().piehip_bench_ntt(self._h, nlimbs, mod_count or self.M, int(inverse), iters, C.byref(ms)))
+        _check(lib().piehip_bench_ntt(self._h, nlimbs, mod_count or self.M, int(inverse) | (2 if lane_order else 0), iters, C.byref(ms)))
         return ms.value
 
     def set_run_streams(self, n):
@@ -203,7 +204,12 @@ class BatchedFHEHIPPIE:
 
     def __init__(self, cryptoContext, vectorizedHCT=None, preCalcRandomMask=None, slots=None, mask_slots=None,
                  serverStashSize=0, simpleMultiTables=True, cuckooMultiTables=True, serverSet=None, hashParams=None,
-                 hashTable=None, shuffle_seed=2, mask_seed=3):
+                 hashTable=None, shuffle_seed=None, mask_seed=None):
+        # Seeds of the Cuckoo evictions, the bin-layer shuffle and the random masks: secret by default (OS CSPRNG), as the
+        # reference draws them from std::random_device (BatchedFHEHIPPIE.cpp:25-26,72-82; CuckooHashTable.cpp:51-52).
+        # The masks hide prod_h(item - x) of non-matching slots from the client.  Explicit seeds are for parity tests.
+        def secret(v):
+            return secrets.randbits(64) if v is None else int(v)
         if serverStashSize != 0:
             raise ValueError("Error, batched FHE PIE does not support a stash (yet).")
         if not simpleMultiTables or not cuckooMultiTables:
@@ -218,13 +224,14 @@ class BatchedFHEHIPPIE:
             items, ip = _u64(serverSet)
             self.K, self.b, self.E = p["K"], p["b"], p["E"]
             _check(lib().piehip_build_db(h, ip, len(items), p["k"], p["e"], p["K"], p["b"], p["E"], p.get("hash_seed", 987654321),
-                                         p.get("evict_seed", 1), p.get("shuffle_seed", 2), p.get("mask_seed", 3)))
+                                         secret(p.get("evict_seed")), secret(p.get("shuffle_seed", shuffle_seed)),
+                                         secret(p.get("mask_seed", mask_seed))))
             self._tbl_shape = (p["k"], p["e"], p["K"], p["b"], p["E"])
         elif hashTable is not None:
             # the reference constructor proper: hct.hierarchicalCuckooTable [k][e][K][b][E] -> shuffle, gather, encode
             tbl, tp = _u64(hashTable)
             k, e, self.K, self.b, self.E = tbl.shape
-            _check(lib().piehip_load_db_table(h, tp, k, e, self.K, self.b, self.E, shuffle_seed, mask_seed))
+            _check(lib().piehip_load_db_table(h, tp, k, e, self.K, self.b, self.E, secret(shuffle_seed), secret(mask_seed)))
             self._tbl_shape = tbl.shape
         elif vectorizedHCT is not None:
             db, dbp = _u64(vectorizedHCT)
@@ -328,14 +335,15 @@ class FHEHIPPIE:
         self.npie, self.K, self.b, self.E = tbl.shape
         if self.b != self.E:
             raise ValueError("Error, for FHE PIE the size of a cuckoo bin has to be equal than the number of bins per hash function.")
-        rng = np.random.default_rng(perm_seed) if perm_seed is not None else None
+        rng = None if perm_seed is False else np.random.default_rng(secrets.randbits(128) if perm_seed is None else perm_seed)
         self.permVec2 = np.stack([rng.permutation(self.b) if rng is not None else np.arange(self.b) for _ in range(self.npie)])
         self.permutationVector = np.stack([rng.permutation(self.K) if rng is not None else np.arange(self.K) for _ in range(self.npie)])
         slots = np.ones((self.npie, self.K, self.b, self.E + 1), dtype=np.int64)  # last slot: exponent of the "minus client" element
         for i in range(self.npie):
             slots[i, :, self.permVec2[i], :self.E] = tbl[i].astype(np.int64).transpose(1, 0, 2)
         if masks is None:
-            masks = np.random.default_rng(mask_seed).integers(1, self.cc.t, size=(self.npie, self.K, self.b), dtype=np.int64)
+            mrng = np.random.default_rng(secrets.randbits(128) if mask_seed is None else mask_seed)
+            masks = mrng.integers(1, self.cc.t, size=(self.npie, self.K, self.b), dtype=np.int64)
         self.masks = np.ascontiguousarray(masks, dtype=np.int64).reshape(self.npie, self.K, self.b)
         self.slots = np.ascontiguousarray(slots)
         _check(lib().piehip_fhepie_load_table(self.cc._h, self.npie, self.K, self.b, self.E, self.slots.ctypes.data_as(i64p),

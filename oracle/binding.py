@@ -26,6 +26,31 @@ def build(force=False):
     return _LIB_PATH
 
 
+BUILD_FLAGS = "-O3 (portable; shipped oracle/libpieoracle.so)"
+
+
+def prefer_native(outdir=None):
+    """bench.py's cpu_baseline leg: rebuild the oracle with -O3 -march=native on the host that is about to time it
+     and load that instead of the portable library that travelled here.  Must be called before
+    the first lib() call; falls back to the portable build (and says so) when no compiler is available.
+    Returns the flags actually in use."""
+    global _LIB_PATH, BUILD_FLAGS
+    if _lib is not None:
+        return BUILD_FLAGS
+    import tempfile
+    out = os.path.join(outdir or tempfile.mkdtemp(prefix="pieoracle_"), "libpieoracle_native.so")
+    cmd = ["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-fno-strict-aliasing", "-shared", "-o", out,
+           os.path.join(_HERE, "pie_oracle.c"), os.path.join(_HERE, "pie_hashing.c")]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        C.CDLL(out)  # loadable on this host?
+        _LIB_PATH = out
+        BUILD_FLAGS = "gcc -O3 -march=native, compiled on the host it is timed on"
+    except (OSError, subprocess.CalledProcessError):
+        pass
+    return BUILD_FLAGS
+
+
 def _p(a, ty=u64p):
     if a is None:
         return None

@@ -18,3 +18,10 @@ def ob():
     from oracle import binding
     binding.build()
     return binding
+
+
+@pytest.fixture(scope="session")
+def pie_mod():
+    """the product's host mirror (nested_hashing_psi_amd.pie over libpiehip.so)"""
+    from nested_hashing_psi_amd import pie
+    return pie

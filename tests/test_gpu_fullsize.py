@@ -1,20 +1,33 @@
-"""Full-size checks at the BASELINE.json configurations, on the GPU.
+"""Every BASELINE.json configuration at its full size on the GPU, against the oracle.
 
-C3 (N=16384, 4 RNS primes, |S|=2^20, |C|=2^10, k=2,e=4949,K=2,E=14,b=14; Parameters1.txt:11):
-a real query end to end -- nested hashing of 2^20 server items, packing on the device, secret-key
-encrypted index matrix, run() on the GPU -- must (a) equal the oracle's restated run() bit for bit and
-(b) decrypt to exactly the true intersection (reference check: PSIClient.hpp:142-164).
-C2 likewise at N=8192 / 3 primes / |S|=2^16.  C5's ring (N=32768, 6 primes, K=3) is exercised with its
-real depth on a reduced database (the full 4 GiB database adds nothing the smaller one does not test).
+Each case is a real query end to end: the server set goes through the device's offline phase (nested hashing, Cuckoo
+insertion, bin shuffle, gather, packed encoding: piehip_build_db), the client's one-hot index matrix and minus vector are
+secret-key encrypted, run() evaluates them on the GPU, and the result must
+  (a) equal the oracle's restated run() (oracle/pie_oracle.c, reference BatchedFHEHIPPIE.cpp:88-129) bit for bit on the
+      bin layers compared -- all of them for C1, C2, C3; layers from both ends of each queue group for C5 (the oracle
+      needs 0.5 s per C5 layer);
+  (b) decrypt, with a positive noise budget in every result, to exactly the true intersection (reference check:
+      src/Client/PSIClient.hpp:142-164);
+and the device-built hash table must equal the oracle's (same seeds).  "Bit for bit" is relative to the in-tree oracle:
+parity with OpenFHE itself is unpinned.
+
+  C1  N=4096,  2 primes, t=65537,      |S|=2^12, |C|=2^8,  k=3 e=110   K=2 E=7  b=7    (derived)
+  C2  N=8192,  3 primes, t=4296540161, |S|=2^16, |C|=2^10, k=3 e=443   K=2 E=12 b=12   (Parameters1.txt:53)
+  C3  N=16384, 4 primes,               |S|=2^20, |C|=2^10, k=2 e=4949  K=2 E=14 b=14   (Parameters1.txt:11)
+  C5  N=32768, 6 primes,               |S|=2^24, |C|=2^12, k=2 e=13004 K=3 E=30 b=30   (Parameters1.txt:19 with -K 3)
+  KAT-0 at the reference test's own parameters: tests/TestBatchedFHEPIE.cpp:14-41,89-94 (N=16384, 33-bit t).
+C4 (C3's bin layers over several GPUs) is tests/test_sharding_gpu.py.
 """
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+T16 = 65537
 T32 = 4296540161
+SEEDS = dict(hash_seed=987654321, evict_seed=1, shuffle_seed=2, mask_seed=3)
 
 
-def run_case(ob, pie, N, L, t, nS, nC, k, e, K, E, b, seed):
+def run_case(ob, pie, N, L, t, nS, nC, k, e, K, E, b, seed, compare_layers, streams=0):
     o = ob.Oracle(N, L, t)
     rng = np.random.default_rng(seed)
     items = np.unique(rng.integers(1, t, nS + nC + 4096, dtype=np.uint64))
@@ -23,26 +36,32 @@ def run_case(ob, pie, N, L, t, nS, nC, k, e, K, E, b, seed):
     ninter = nC // 2 + 1
     client = np.concatenate([server[:ninter], items[nS:nS + nC - ninter]])
     rng.shuffle(client)
-    tab = ob.Tabulation(987654321, k + K)
-    tbl = ob.hct_build(tab, server, k, e, K, b, E, evict_seed=1)
-    ob.hct_shuffle_bins(tbl, 2)
+    # oracle side of the offline phase
+    tab = ob.Tabulation(SEEDS["hash_seed"], k + K)
+    tbl = ob.hct_build(tab, server, k, e, K, b, E, evict_seed=SEEDS["evict_seed"])
+    ob.hct_shuffle_bins(tbl, SEEDS["shuffle_seed"])
     slots = ob.pack_db(tbl)
-    mask_slots = ob.masks(t, b, k * e, 3)
+    mask_slots = ob.masks(t, b, k * e, SEEDS["mask_seed"])
+    # client
     ctab = ob.client_build(tab, client, k, e, evict_seed=4)
     index, minus_v = ob.client_vectors(tab, ctab, K, E)
     sk = o.keygen(11)
     evk = o.relin_keygen(sk, 12)
     idx = np.stack([o.encrypt_slots(sk, index[h, j], 100 + h * E + j) for h in range(K) for j in range(E)]).reshape(K, E, 2, L, N)
     minus = o.encrypt_slots(sk, minus_v, 99)
+    # device: whole offline phase from the raw server set, then the query
     cc = pie.PieContext(N, L, t)
     cc.load_relin_key(evk)
-    op = pie.BatchedFHEHIPPIE(cc, slots=slots, mask_slots=mask_slots)
+    cc.set_run_streams(streams)
+    op = pie.BatchedFHEHIPPIE(cc, serverSet=server, hashParams=dict(k=k, e=e, K=K, b=b, E=E, **SEEDS))
+    assert (op.hashTable() == tbl).all()
+    del tbl
     op.setMinusCompareElement(minus)
     op.setIndex(idx)
     op.run()
-    got = op.getResultList()
+    got = op.getResultList().copy()
     cc.close()
-    # decrypted semantics: exactly the intersection, positive noise budget in every result
+    # (b) decrypted semantics on every bin layer
     dec, budgets = [], []
     for bn in range(b):
         d, bud = o.decrypt_slots(sk, got[bn], k * e)
@@ -50,32 +69,87 @@ def run_case(ob, pie, N, L, t, nS, nC, k, e, K, E, b, seed):
         budgets.append(bud)
     assert min(budgets) > 0
     found = ob.client_scan(ctab, np.stack(dec))
+    assert len(found) == ninter
     assert sorted(int(v) for v in found) == sorted(int(v) for v in server[:ninter])
-    return o, got, idx, minus, slots, mask_slots, evk
-
-
-def test_c3_headline_config_bit_exact_and_intersection(ob):
-    from nested_hashing_psi_amd import pie
-    N, L, K, E, b = 16384, 4, 2, 14, 14
-    o, got, idx, minus, slots, mask_slots, evk = run_case(ob, pie, N, L, T32, 1 << 20, 1 << 10, 2, 4949, K, E, b, 123456789)
-    # bit-exact against the oracle on a subset of bin layers (the oracle needs ~70 ms per layer)
-    for lo, hi in ((0, 2), (b - 2, b)):
-        db = np.stack([o.encode_eval(slots[h, bn, j]) for h in range(K) for bn in range(lo, hi) for j in range(E)]).reshape(K, hi - lo, E, L, N)
-        masks = np.stack([o.encode_eval(mask_slots[bn]) for bn in range(lo, hi)])
+    # (a) ciphertext bits
+    for bn in compare_layers:
+        db = np.stack([o.encode_eval(slots[h, bn, j]) for h in range(K) for j in range(E)]).reshape(K, 1, E, L, N)
+        masks = o.encode_eval(mask_slots[bn])[None]
         want = o.pie_run(idx, minus, db, masks, evk)
-        assert (got[lo:hi] == want).all()
+        assert (got[bn] == want[0]).all(), "bin layer %d differs from the oracle" % bn
+    return min(budgets)
 
 
-def test_c2_config(ob):
-    from nested_hashing_psi_amd import pie
-    run_case(ob, pie, 8192, 3, T32, 1 << 16, 1 << 10, 3, 443, 2, 12, 12, 7)
+def test_c1_plumbing_config_all_layers(ob, pie_mod):
+    run_case(ob, pie_mod, 4096, 2, T16, 1 << 12, 1 << 8, 3, 110, 2, 7, 7, 5, range(7))
 
 
-def test_c5_ring_and_depth(ob):
-    """N=32768, 6 primes, K=3 (two chained ct x ct), reduced |S|: outer-stage-folded 2^14 slices"""
-    from nested_hashing_psi_amd import pie
-    N, L, K, E, b = 32768, 6, 3, 6, 4
-    o, got, idx, minus, slots, mask_slots, evk = run_case(ob, pie, N, L, T32, 1 << 13, 1 << 10, 2, 2000, K, E, b, 99)
-    db = np.stack([o.encode_eval(slots[h, bn, j]) for h in range(K) for bn in range(1) for j in range(E)]).reshape(K, 1, E, L, N)
-    masks = np.stack([o.encode_eval(mask_slots[bn]) for bn in range(1)])
-    assert (got[:1] == o.pie_run(idx, minus, db, masks, evk)).all()
+def test_c2_config_all_layers(ob, pie_mod):
+    run_case(ob, pie_mod, 8192, 3, T32, 1 << 16, 1 << 10, 3, 443, 2, 12, 12, 7, range(12))
+
+
+def test_c3_headline_config_all_layers(ob, pie_mod):
+    run_case(ob, pie_mod, 16384, 4, T32, 1 << 20, 1 << 10, 2, 4949, 2, 14, 14, 123456789, range(14))
+
+
+def test_c3_serial_queue_all_layers(ob, pie_mod):
+    """the same query with run() on one queue (what bench.py --streams 1 and the per-kernel profile passes execute)"""
+    run_case(ob, pie_mod, 16384, 4, T32, 1 << 20, 1 << 10, 2, 4949, 2, 14, 14, 123456789, range(14), streams=1)
+
+
+def test_c5_full_size(ob, pie_mod):
+    """|S| = 2^24 hashed on the device (e = 13004 positions, B = 26008 slots > 2^14), 2700 + 30 plaintexts encoded (4 GiB
+    resident), E = 30 terms per inner product (the 128-bit stage-A kernel, not the carry-free one), K = 3 (two chained
+    ct x ct), L = 6 base conversions on folded 2^14 slices, 30 bin layers split over the run queues."""
+    b = 30
+    # first, last and the layers either side of every plausible queue split (run() splits 17 + 13 today)
+    layers = sorted({0, 1, b // 2 - 1, b // 2, (4 * b + 3) // 7 - 1, (4 * b + 3) // 7, b - 2, b - 1})
+    budget = run_case(ob, pie_mod, 32768, 6, T32, 1 << 24, 1 << 12, 2, 13004, 3, 30, b, 2024, layers)
+    assert budget > 0
+
+
+@pytest.mark.parametrize("N,L,t", [(4096, 2, T16), (16384, 4, T32)])
+@pytest.mark.parametrize("equals", [True, False])
+def test_kat0_reference_test_on_the_gpu(ob, pie_mod, N, L, t, equals):
+    """tests/TestBatchedFHEPIE.cpp:54-149 on the GPU, at a 2-prime ring that fits t = 65537 and at the reference test's
+    own parameters (:14-41: ring 16384, plaintext modulus 4296540161): k=2, e=1, K=2, E=10, b=20, 100 items; the index
+    matrix is built by hand with BOTH slots selecting the element (:101-124).  "Test should output matches twice"
+    (:73); none when the element is not in the set (:72-82).  Ciphertexts equal the oracle's bit for bit."""
+    pie = pie_mod
+    from tests.test_oracle_pie import distinct_items
+    o = ob.Oracle(N, L, t)
+    rng = np.random.default_rng(122333444455555 % (1 << 32))
+    items = distinct_items(rng, t, 100)
+    k, e, K, E, b = 2, 1, 2, 10, 20
+    present = set(int(x) for x in items)
+    elem = int(items[50]) if equals else next(v for v in range(1, t) if v not in present)
+    sk = o.keygen(1)
+    evk = o.relin_keygen(sk, 2)
+    tab = ob.Tabulation(12223222, k + K)
+    tbl = ob.hct_build(tab, items, k, e, K, b, E, evict_seed=5)
+    idx = np.zeros((K, E, 2, L, N), dtype=np.uint64)
+    for h in range(K):
+        hi = tab.hash(elem, k + h) % E
+        for j in range(E):
+            idx[h, j] = o.encrypt_slots(sk, [1, 1] if j == hi else [0, 0], 10 + h * E + j)
+    minus = o.encrypt_slots(sk, [-elem, -elem], 9)
+    cc = pie.PieContext(N, L, t)
+    cc.load_relin_key(evk)
+    op = pie.BatchedFHEHIPPIE(cc, hashTable=tbl, shuffle_seed=6, mask_seed=7)   # the reference constructor on the device
+    op.setMinusCompareElement(minus)
+    op.setIndex(idx)
+    op.run()
+    got = op.getResultList().copy()
+    cc.close()
+    ob.hct_shuffle_bins(tbl, 6)
+    slots = ob.pack_db(tbl)
+    db = np.stack([o.encode_eval(slots[h, bn, j]) for h in range(K) for bn in range(b) for j in range(E)]).reshape(K, b, E, L, N)
+    mk = ob.masks(t, b, 2, 7)
+    masks = np.stack([o.encode_eval(mk[bn]) for bn in range(b)])
+    assert (got == o.pie_run(idx, minus, db, masks, evk)).all()
+    matches = 0
+    for bn in range(b):
+        dec, budget = o.decrypt_slots(sk, got[bn], 2)
+        assert budget > 0
+        matches += int((dec == 0).sum())
+    assert matches == (2 if equals else 0)

@@ -376,7 +376,7 @@ def test_fhepie_bit_exact_and_semantics(ob, pie, N, L, t, K, E):
     for r in c["keys"]:
         assert cc.rotation_galois(r) == o.rot_index(r)
     cc.load_rotation_keys(c["keys"])
-    op = pie.FHEHIPPIE(cc, c["tbl"], perm_seed=None, masks=c["masks"])
+    op = pie.FHEHIPPIE(cc, c["tbl"], perm_seed=False, masks=c["masks"])
     assert (op.slots[0] == c["slots"]).all()
     op.setIndex(c["idx"])
     op.run()

@@ -126,6 +126,30 @@ def test_kat2_end_to_end_intersection(ob, N, L, t, nS, nC, k, e, K, E, b):
     assert (part[: b // 2] == res[: b // 2]).all() and (part2[b // 2:] == res[b // 2:]).all()
 
 
+def test_c1_baseline_config_at_full_size(ob):
+    """BASELINE.json config 1 on the oracle alone (its "plumbing, no GPU" case): N=4096, 2 primes, t=65537 (a 33-bit t
+    does not fit two primes), |S|=2^12, |C|=2^8, k=3, e=110, K=2, E=b=7 (derived per BASELINE.md
+    section 3).  The intersection of 129 items comes back exactly, with noise budget to spare."""
+    N, L, t = 4096, 2, T16
+    nS, nC, k, e, K, E, b = 1 << 12, 1 << 8, 3, 110, 2, 7, 7
+    o = ob.Oracle(N, L, t)
+    rng = np.random.default_rng(5)
+    universe = distinct_items(rng, t, nS + nC)
+    server = universe[:nS].copy()
+    ninter = nC // 2 + 1
+    client = np.concatenate([server[:ninter], universe[nS:nS + nC - ninter]])
+    rng.shuffle(client)
+    sk = o.keygen(11)
+    evk = o.relin_keygen(sk, 12)
+    d = pie_inputs(ob, o, sk, server, client, k, e, K, E, b, hash_seed=987654321)
+    res = o.pie_run(d["idx"], d["minus"], d["db"], d["masks"], evk)
+    outs = [o.decrypt_slots(sk, res[bn], d["B"]) for bn in range(b)]
+    assert min(bud for _, bud in outs) > 0
+    got = ob.client_scan(d["ctab"], np.stack([dec for dec, _ in outs]))
+    assert len(got) == ninter == 129
+    assert sorted(int(x) for x in got) == sorted(int(x) for x in server[:ninter])
+
+
 def test_tabulation_hash_is_std_mt19937(ob):
     """TabulationHashing.cpp:22-33: std::mt19937(seed) + uniform_int_distribution<uint64_t>.
     First outputs of mt19937(5489) are 3499211612, 581869302 (the C++ standard's check value

@@ -56,6 +56,21 @@ int main()
             threw = true;
         }
         if (!threw) bad |= 16;
+        // residues must be canonical: one word at its modulus is rejected, all words below it are accepted
+        {
+            const uint64_t q[2] = {1000003, 1000033};
+            std::vector<uint64_t> ok(ct);
+            for (size_t i = 0; i < ok.size(); i++) ok[i] = i % 1000003;
+            if (unpackCiphertexts(packCiphertexts(ok.data(), 1, L, N), L, N, got, q) != 1) bad |= 64;
+            ok[3 * (size_t)N + 5] = q[1];  // limb 3 = component 1, tower 1
+            threw = false;
+            try {
+                unpackCiphertexts(packCiphertexts(ok.data(), 1, L, N), L, N, got, q);
+            } catch (const std::invalid_argument &) {
+                threw = true;
+            }
+            if (!threw) bad |= 64;
+        }
     } catch (const std::exception &e) {
         std::printf("server: %s\n", e.what());
         bad |= 32;

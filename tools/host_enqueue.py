@@ -1,5 +1,5 @@
 """Host-side cost of enqueueing run() (no sync) vs the GPU time of the same K runs, per stream count.
-Usage on the GPU box: PIEHIP_STREAMS=n python tools/host_enqueue.py"""
+Usage on the GPU box: python tools/host_enqueue.py [queues]"""
 import os
 import sys
 import time
@@ -26,6 +26,8 @@ op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=limbs(rng, cc.q, (K, b, E), N), preC
 cc.load_relin_key(limbs(rng, cc.q, (L, 2), N))
 op.setIndex(limbs(rng, cc.q, (K, E, 2), N))
 op.setMinusCompareElement(limbs(rng, cc.q, (2,), N))
+nq = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+cc.set_run_streams(nq)
 for _ in range(20):
     op.run(sync=False)
 op.sync()
@@ -36,4 +38,4 @@ for _ in range(n):
 t1 = time.perf_counter()
 op.sync()
 t2 = time.perf_counter()
-print("streams=%s host enqueue %.1f us/run, total %.1f us/run" % (os.environ.get("PIEHIP_STREAMS", "default"), (t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6))
+print("streams=%s host enqueue %.1f us/run, total %.1f us/run" % (nq or "default", (t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6))
