@@ -6,11 +6,13 @@ times at src/Server/FHE/BatchedFHEPSIServer.cpp:98-106) over one synthetic query
 resident in HBM.  Metric: result ciphertexts per second (b / t_run), whole job.
 
   python bench.py --gpus 1 --steps K --warmup W            (N=1: config C3 of BASELINE.json)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (config C4)
 
-Multi-GPU: bin layers are independent, so every rank owns a shard of bin layers
-(weak scaling: each rank evaluates the b layers of its own |S|=2^20 server shard against the same
-query); the only collective is the final RCCL all-gather of the result ciphertexts.
+Multi-GPU (BASELINE config C4): bin layers are independent, so the b = 14 bin layers of the C3 database are
+split over the ranks (strong scaling, the default for N > 1; speed-up is capped at b / ceil(b / N)); the only collective
+is the RCCL gather of the result ciphertexts to rank 0.  --scaling weak gives every rank its own b layers instead.
+At N = 1 the line also carries `projected_strong_scaling`: the time of one rank's share ceil(b / G) of the bin layers,
+measured on this GPU, for G = 2, 4, 8 and for the balanced parameter rows SURVEY 8e names.
 
 Synthetic data: the arithmetic is data-independent, so index/minus ciphertexts and the
 relinearisation key are uniform residues (what real ones are indistinguishable from) and the
@@ -50,6 +52,7 @@ def cpu_baseline(cfg, seconds_target=12.0, max_threads=16):
     """The oracle (a CPU restatement of the reference path -- OpenFHE itself is not available)
     timed on this host, one core, on a bounded sample of the same workload."""
     from oracle import binding as ob
+    build_flags = ob.prefer_native()   # -O3 -march=native on the host that is timed (BASELINE.md section 3), else the shipped build
     N, L, t, K, E, b = cfg["N"], cfg["L"], cfg["t"], cfg["K"], cfg["E"], cfg["b"]
     o = ob.Oracle(N, L, t)
     rng = np.random.default_rng(1)
@@ -73,14 +76,14 @@ def cpu_baseline(cfg, seconds_target=12.0, max_threads=16):
         o.pie_run(idx, minus, db1, m1, evk)
         done += 1
     dt = time.perf_counter() - t0
-    out = {"value": done / dt, "unit": "ciphertexts/s", "cores": 1, "kind": "port",
+    out = {"value": done / dt, "unit": "ciphertexts/s", "cores": 1, "kind": "port", "build": build_flags, "host": host_cpu_info(),
            "sample": "%d bin layers of the %s workload (K=%d, E=%d; 1 ct x ct + %d ct x pt MACs each), %.1f s; "
                      "CPU restatement in C (oracle/), OpenFHE not available" % (done, cfg["name"], K, E, K * E, dt)}
     # (b) of SURVEY 8d: the same work on every core this process may use, one bin layer per task (bin layers are
     # independent; the C call releases the GIL)
     import concurrent.futures
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, max_threads)  # the GPU box grants a one-GPU job 16 CPUs' worth of time whatever the affinity mask says
+    cores = min(cores, max_threads)  # the GPU box grants a one-GPU job 16 CPUs' worth of time whatever the affinity mask says (see "host")
     if cores > 1:
         ntask = int(max(cores, min(64 * b, 0.5 * seconds_target / per_bin * cores)))
         t0 = time.perf_counter()
@@ -128,6 +131,31 @@ def cpu_baseline(cfg, seconds_target=12.0, max_threads=16):
     return out
 
 
+def host_cpu_info():
+    """what the CPU legs could use on this host: logical CPUs, this process's affinity mask, the cgroup CPU quota"""
+    info = {"host_cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "cgroup_quota_cpus": None, "model": None}
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:      # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()
+            info["cgroup_quota_cpus"] = None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        try:
+            q_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            info["cgroup_quota_cpus"] = None if q_ < 0 else q_ / p_
+        except (OSError, ValueError):
+            pass
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                info["model"] = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return info
+
+
 def e2e_psi(cfg, pie, cc, device_sync):
     """End-to-end PSI wall-clock (the second half of BASELINE.json's metric), in process, no TCP: what the
     reference client times as Setup + Offline + Online (src/Client/PSIClient.hpp:87-116).  Server offline phase
@@ -149,6 +177,7 @@ def e2e_psi(cfg, pie, cc, device_sync):
     cl = BatchedFHEPSIClient(cc, k, e, K, E, b)
     evk = cl.runSetUpPhase()
     cc.load_relin_key(evk)
+    cc.reserve(nS, k, e, K, b, E)     # sizes are known at set-up (HashTableParameter): the offline phase allocates nothing
     device_sync()
     t1 = time.perf_counter()
     srv = pie.BatchedFHEHIPPIE(cc, serverSet=server, hashParams=dict(k=k, e=e, K=K, b=b, E=E))
@@ -195,17 +224,119 @@ def pmc_traffic(config):
     return None
 
 
+# parameter rows for the projected strong scaling (SURVEY 8e "Limits"): the headline row (cap 7x at 8 GPUs), a row with a
+# bin count that 8 divides, and the reference's own k = 3 row of this set size (Parameters1.txt:59)
+SCALING_ROWS = {
+    "C3 b=14 E=14": dict(k=2, e=4949, K=2, E=14, b=14),
+    "b=16 E=13": dict(k=2, e=4949, K=2, E=13, b=16),
+    "k=3 e=443 b=40 E=40 (Parameters1.txt:59)": dict(k=3, e=443, K=2, E=40, b=40),
+}
+
+
+def synthetic_operator(pie, cc, cfg, b_local, rng, device_inputs):
+    """an operator over b_local bin layers of synthetic database content (uniform slot values, packed on the device),
+    inputs already resident"""
+    t, K, E, B = cfg["t"], cfg["K"], cfg["E"], cfg["k"] * cfg["e"]
+    slots = rng.integers(0, t, (K, b_local, E, B), dtype=np.int64)
+    slots[slots > t // 2] -= t
+    mask_slots = rng.integers(1, t, (b_local, B), dtype=np.int64)
+    mask_slots[mask_slots > t // 2] -= t
+    op = pie.BatchedFHEHIPPIE(cc, slots=slots, mask_slots=mask_slots)  # packed + NTT'd on the device
+    idx, minus = device_inputs
+    op.setIndexDevice(idx.data_ptr())
+    op.setMinusCompareElementDevice(minus.data_ptr())
+    return op
+
+
+def time_runs(op, steps, warmup, sync):
+    for _ in range(warmup):
+        op.run(sync=False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        op.run(sync=False)
+    sync()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, steps, warmup, t_full_ms):
+    """SURVEY 8e without an 8-GPU box: a rank of G owns ceil(b / G) bin layers (the slowest rank sets the time), so
+    speed-up(G) = t(b) / t(ceil(b / G)), every t measured here on one GPU with the same kernels, queues and launch path.
+    Leaves out the result gather (b * 2LW bytes in total, each slice over its own xGMI link) and the broadcast of the query."""
+    out = {"note": "t(n) = ms per run() over n bin layers on this one GPU; speedup(G) = t(b) / t(ceil(b/G)); excludes the RCCL "
+                   "gather of b*2LW result bytes and the query broadcast; cap = b / ceil(b/G)", "rows": {}}
+    N, L, t = cfg["N"], cfg["L"], cfg["t"]
+    for name, row in SCALING_ROWS.items():
+        c2 = dict(cfg, **row)
+        b = c2["b"]
+        shares = sorted({-(-b // G) for G in (1, 2, 4, 8)}, reverse=True)
+        tms = {}
+        for n in shares:
+            if name.startswith("C3") and n == b and t_full_ms is not None:
+                tms[n] = t_full_ms
+                continue
+            stream = torch.cuda.Stream(device)
+            cc = pie.PieContext(N, L, t, device=local_rank, stream=stream.cuda_stream)
+            evk = uniform_limbs(torch, (L, 2), cc.q, N, device, gen)
+            idx = uniform_limbs(torch, (c2["K"], c2["E"], 2), cc.q, N, device, gen)
+            minus = uniform_limbs(torch, (2,), cc.q, N, device, gen)
+            cc.load_relin_key(evk.cpu().numpy().view(np.uint64))
+            op = synthetic_operator(pie, cc, c2, n, np.random.default_rng(n), (idx, minus))
+            tms[n] = time_runs(op, steps, warmup, lambda: torch.cuda.synchronize(device))
+            cc.close()
+            del op, cc, idx, minus, evk
+        out["rows"][name] = {"b": b, "E": c2["E"], "ms_per_run": {str(n): tms[n] for n in shares},
+                             "speedup": {str(G): tms[b] / tms[-(-b // G)] for G in (2, 4, 8)},
+                             "cap": {str(G): b / -(-b // G) for G in (2, 4, 8)}}
+    return out
+
+
+def reference_timer(torch, op, idx, minus, b, iters, device):
+    """The reference's own timer placement (BatchedFHEPSIServer.cpp:98-106): setMinusCompareElement + setIndex + run, with the
+    query in HOST memory as the deserialised ciphertexts are -- so this includes the PCIe upload that `value` leaves out.
+    (a) run complete on the device; (b) result list also back in host memory (what sendResult needs, .cpp:108)."""
+    idx_h = idx.cpu().numpy().view(np.uint64)
+    minus_h = minus.cpu().numpy().view(np.uint64)
+    ta, tb = [], []
+    for _ in range(iters + 2):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        op.setMinusCompareElement(minus_h)
+        op.setIndex(idx_h)
+        op.run(sync=True)
+        t1 = time.perf_counter()
+        op.getResultList()
+        t2 = time.perf_counter()
+        ta.append(t1 - t0)
+        tb.append(t2 - t0)
+    ta, tb = sorted(ta[2:]), sorted(tb[2:])
+    # leave the operator as the timed region expects it: inputs resident
+    op.setIndexDevice(idx.data_ptr())
+    op.setMinusCompareElementDevice(minus.data_ptr())
+    med_a, med_b = ta[len(ta) // 2], tb[len(tb) // 2]
+    return {"ms": med_a * 1e3, "ms_with_results_on_host": med_b * 1e3, "value": b / med_a, "value_with_results_on_host": b / med_b,
+            "unit": "ciphertexts/s", "iters": iters,
+            "what": "median host wall of setMinusCompareElement(host) + setIndex(host) + run() + sync, query = %d ciphertexts "
+                    "(%.1f MiB) in pageable host memory; second figure adds getResultList (%.1f MiB back)"
+                    % (idx_h.shape[0] * idx_h.shape[1] + 1, (idx_h.nbytes + minus_h.nbytes) / 2**20, b * minus_h.nbytes / 2**20)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N > 1: strong (default; BASELINE config C4: the b bin layers split over the ranks) or weak (b layers per rank)")
+    ap.add_argument("--bins-per-rank", type=int, default=0,
+                    help="one GPU: evaluate only n bin layers per run() -- the share of one rank of ceil(b/n) GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the multi-core leg of the CPU baseline")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end PSI wall-clock leg")
+    ap.add_argument("--no-projection", action="store_true", help="skip the projected strong-scaling legs")
+    ap.add_argument("--no-ref-timer", action="store_true", help="skip the host-inputs (reference timer placement) leg")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams run() spreads the bin layers over (0 = library default, 1 = serial: every kernel alone on the GPU)")
     ap.add_argument("--collective", default="auto", choices=["auto", "gather", "all_gather"],
@@ -244,98 +375,73 @@ def main():
     cfg = dict(CONFIGS[args.config], name=args.config)
     N, L, t, K, E, b = cfg["N"], cfg["L"], cfg["t"], cfg["K"], cfg["E"], cfg["b"]
     B = cfg["k"] * cfg["e"]
-    if args.scaling == "strong" and world > 1:
+    scaling = args.scaling or ("strong" if world > 1 else "weak")   # one GPU: the two coincide
+    if scaling == "strong" and world > 1:
         lo, hi = shard.bin_slice(b, rank, world)
         b_local = hi - lo
+        b_total = b
     else:
         b_local = b
-    b_total = b_local * world if args.scaling == "weak" else b
+        b_total = b * world
+    if args.bins_per_rank and world == 1:
+        b_local = b_total = min(b, args.bins_per_rank)
 
-    stream = torch.cuda.current_stream(device)
+    # the context's stream: a non-default torch stream, so that torch / RCCL work queued under it and the library's own
+    # queues order against each other through the same stream (the null stream does not order against non-blocking ones)
+    stream = torch.cuda.Stream(device)
     cc = pie.PieContext(N, L, t, device=local_rank, stream=stream.cuda_stream)
     gen = torch.Generator(device=device)
-    gen.manual_seed(123456789 + rank)
+    gen.manual_seed(123456789)                 # the query and the key are the same on every rank
     rng = np.random.default_rng(987654321 + rank)
     # relinearisation key and per-query inputs: resident in HBM before the timed region
     evk = uniform_limbs(torch, (L, 2), cc.q, N, device, gen)
     idx = uniform_limbs(torch, (K, E, 2), cc.q, N, device, gen)
     minus = uniform_limbs(torch, (2,), cc.q, N, device, gen)
+    torch.cuda.synchronize(device)
     cc.load_relin_key(evk.cpu().numpy().view(np.uint64))
-    op = None
-    if b_local > 0:
-        slots = rng.integers(0, t, (K, b_local, E, B), dtype=np.int64)
-        slots[slots > t // 2] -= t
-        mask_slots = rng.integers(1, t, (b_local, B), dtype=np.int64)
-        mask_slots[mask_slots > t // 2] -= t
-        op = pie.BatchedFHEHIPPIE(cc, slots=slots, mask_slots=mask_slots)  # packed + NTT'd on the device
-        op.setIndexDevice(idx.data_ptr())
-        op.setMinusCompareElementDevice(minus.data_ptr())
+    op = synthetic_operator(pie, cc, cfg, b_local, rng, (idx, minus)) if b_local > 0 else None
     cc.set_run_streams(args.streams)
     ct_words = 2 * L * N
-    gathered = my_out = works = None
+    rg = None
     if use_dist:
-        # gather buffers allocated once, outside the timed region; two sets so that the gather of query i
-        # (RCCL's own stream) overlaps run() of query i+1 (a server answers a stream of queries)
-        bmax = shard.max_bins(b, world) if args.scaling == "strong" else b_local
-        my_out = [torch.zeros((bmax, ct_words), dtype=torch.int64, device=device) for _ in range(2)]
-        gathered = [torch.empty((world * bmax, ct_words), dtype=torch.int64, device=device) for _ in range(2)]
-        gather_lists = [list(g.view(world, bmax, ct_words).unbind(0)) for g in gathered]
-        works = [None, None]
-    state = {"i": 0}
-
-    def launch_collective(kind, s_):
-        if kind == "gather":
-            return dist.gather(my_out[s_], gather_list=gather_lists[s_] if rank == 0 else None, dst=0, async_op=True)
-        return dist.all_gather_into_tensor(gathered[s_], my_out[s_], async_op=True)
-
-    if use_dist and args.collective == "auto":
-        # both move the same payload; which one RCCL runs faster over this node's xGMI topology is measured, not assumed
-        times = {}
-        for kind in ("gather", "all_gather"):
-            try:
-                for rep in range(6):
-                    if rep == 1:
-                        torch.cuda.synchronize(device)
-                        dist.barrier()
-                        t_ = time.perf_counter()
-                    launch_collective(kind, rep & 1).wait()
-                torch.cuda.synchronize(device)
-                tt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=device)
-                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
-                times[kind] = float(tt_.item())
-            except (RuntimeError, NotImplementedError) as exc:   # every rank fails alike
-                sys.stderr.write("%s unavailable: %s\n" % (kind, exc))
-        # the gather moves 1/world of the all-gather's bytes (less interference with run()): keep it unless clearly slower
-        if "gather" in times and ("all_gather" not in times or times["gather"] <= 1.15 * times["all_gather"]):
-            args.collective = "gather"
-        else:
-            args.collective = "all_gather"
-        if rank == 0:
-            sys.stderr.write("collective timing (5 rounds, s): %s -> %s\n" % (times, args.collective))
+        if args.collective == "auto":
+            # both move the same payload; which one RCCL runs faster over this node's xGMI topology is measured, not assumed
+            times = {}
+            for kind in ("gather", "all_gather"):
+                try:
+                    probe = shard.ResultGather(None, b_total, b_local, ct_words, device, stream, kind=kind)
+                    for rep in range(6):
+                        if rep == 1:
+                            torch.cuda.synchronize(device)
+                            dist.barrier()
+                            t_ = time.perf_counter()
+                        probe.step()
+                    probe.drain()
+                    torch.cuda.synchronize(device)
+                    tt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=device)
+                    dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                    times[kind] = float(tt_.item())
+                    del probe
+                except (RuntimeError, NotImplementedError) as exc:   # every rank fails alike
+                    sys.stderr.write("%s unavailable: %s\n" % (kind, exc))
+            # the gather moves 1/world of the all-gather's bytes (less interference with run()): keep it unless clearly slower
+            if "gather" in times and ("all_gather" not in times or times["gather"] <= 1.15 * times["all_gather"]):
+                args.collective = "gather"
+            else:
+                args.collective = "all_gather"
+            if rank == 0:
+                sys.stderr.write("collective timing (5 rounds, s): %s -> %s\n" % (times, args.collective))
+        rg = shard.ResultGather(op, b_total, b_local, ct_words, device, stream, kind=args.collective)
 
     def step():
-        if not use_dist:
-            if op is not None:
-                op.run(sync=False)
-            return
-        if True:
-            s_ = state["i"] & 1
-            state["i"] += 1
-            if works[s_] is not None:
-                works[s_].wait()                              # buffer set s_ is free again (query i-2 gathered)
-            if op is not None:
-                # results go straight into the gather buffer; the kernel that writes them waits for the line above
-                op.run(sync=False, into=my_out[s_].data_ptr())
-                op.join()                                     # this stream (and the gather behind it) waits for the run
-            # the path's only collective: the result ciphertexts go to rank 0 over each rank's own xGMI link
-            # (--collective all_gather replicates them on every rank: 8x the bytes)
-            works[s_] = launch_collective(args.collective, s_)
+        if rg is not None:
+            rg.step()      # run() into a gather buffer, then the path's only collective, double-buffered
+        elif op is not None:
+            op.run(sync=False)
 
     def drain():
-        if use_dist:
-            for w_ in works:
-                if w_ is not None:
-                    w_.wait()
+        if rg is not None:
+            rg.drain()
 
     for _ in range(args.warmup):
         step()
@@ -393,24 +499,35 @@ def main():
 
     if rank == 0:
         value = b_total / (ms_per_step * 1e-3)
+        cname = "C4 (C3's bin layers over %d GPUs)" % world if (world > 1 and scaling == "strong" and args.config == "C3") else args.config
         line = {
             "metric": "server PIE ciphertexts/sec", "value": value, "unit": "ciphertexts/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%s: BatchedFHEHIPPIE::run(), N=%d, %d RNS primes (60-bit), t=%d, |S|=2^%d |C|=2^%d, k=%d e=%d (B=%d slots), "
-                                   "K=%d E=%d b=%d bin layers per GPU; %d ct x pt MACs + %d ct x ct (HPS + BV relin) + %d mask mults per GPU per step"
-                                   % (args.config, N, L, t, cfg["S"].bit_length() - 1, cfg["C"].bit_length() - 1, cfg["k"], cfg["e"], B, K, E,
-                                      b_local, b_local * K * E, b_local * (K - 1), b_local),
+                                   "K=%d E=%d, b=%d bin layers in all, %d on rank 0; %d ct x pt MACs + %d ct x ct (HPS + BV relin) + %d mask mults per step"
+                                   % (cname, N, L, t, cfg["S"].bit_length() - 1, cfg["C"].bit_length() - 1, cfg["k"], cfg["e"], B, K, E,
+                                      b_total, b_local, b_total * K * E, b_total * (K - 1), b_total),
                        "result_ciphertexts_per_step": b_total, "parallelism": "bins%d" % world,
                        "collective": ("rccl %s of results" % args.collective) if use_dist else "none"},
             "mac_per_s": b_total * K * E / (ms_per_step * 1e-3), "mul_per_s": b_total * (K - 1) / (ms_per_step * 1e-3),
             "run_streams": args.streams if args.streams else 2,
-            # whole run(): algorithmic bytes of the reference's unfused schedule over the measured time
+            # whole run(): algorithmic bytes of the REFERENCE's unfused schedule over the measured time.  Not HBM
+            # utilisation: this build's schedule moves fewer bytes than the formula counts (fused stage A, 95 instead of 111
+            # limb transforms per multiplication), so the fraction says how far the run is from the 8 TB/s bound of that schedule
             "run_roofline": {"alg_bytes_per_run_per_gpu": alg_bytes_run(dict(cfg, b=b_local)),
-                             "achieved_GBps_per_gpu": alg_bytes_run(dict(cfg, b=b_local)) / (ms_per_step * 1e-3) / 1e9,
-                             "frac": alg_bytes_run(dict(cfg, b=b_local)) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                             "ref_schedule_GBps_per_gpu": alg_bytes_run(dict(cfg, b=b_local)) / (ms_per_step * 1e-3) / 1e9,
+                             "ref_schedule_bytes_over_time_frac": alg_bytes_run(dict(cfg, b=b_local)) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "note": "bytes of the reference's unfused schedule / measured time / 8 TB/s; not measured HBM traffic"},
             "roofline": roofline, "kernels": kernels,
         }
+        if world == 1 and op is not None and not args.no_ref_timer:
+            rt = reference_timer(torch, op, idx, minus, b_local, 15, device)
+            line["ref_timer"] = rt
+            line["value_ref_timer"] = rt["value"]
+        if world == 1 and not args.no_projection and args.config == "C3" and not args.bins_per_rank:
+            line["projected_strong_scaling"] = projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, max(20, args.steps // 4),
+                                                                        max(5, args.warmup // 2), ms_per_step if args.streams == 0 else None)
         if not args.no_e2e and world == 1:
             line["e2e_psi"] = e2e_psi(cfg, pie, cc, lambda: torch.cuda.synchronize(device))
         if not args.no_cpu_baseline and world == 1:

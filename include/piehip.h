@@ -90,11 +90,24 @@ int piehip_load_db_slots(piehip_handle h, uint32_t K, uint32_t b, uint32_t E, ui
 #define PIEHIP_EHASH (-5)
 int piehip_build_db(piehip_handle h, const uint64_t *items, size_t n, uint32_t k, uint32_t e, uint32_t K, uint32_t b,
                     uint32_t E, uint64_t hash_seed, uint64_t evict_seed, uint64_t shuffle_seed, uint64_t mask_seed);
+/* Sharded server: the same offline phase, but this handle keeps -- gathers, encodes, evaluates -- only the bin
+ * layers [bin_lo, bin_hi) of the b the table has.  The table itself is built and shuffled whole, so handles given the same
+ * seeds hold slices of one and the same database, and the masks of layer beta are those the unsharded call draws for it. */
+int piehip_build_db_bins(piehip_handle h, const uint64_t *items, size_t n, uint32_t k, uint32_t e, uint32_t K, uint32_t b,
+                         uint32_t E, uint64_t hash_seed, uint64_t evict_seed, uint64_t shuffle_seed, uint64_t mask_seed,
+                         uint32_t bin_lo, uint32_t bin_hi);
+/* Allocates, ahead of the offline phase, everything piehip_build_db(_bins) of this shape and a query need (database, run
+ * workspace, hash table, hashing / packing scratch, input buffers), so that the timed phases do not call hipMalloc.  The
+ * reference server knows these sizes when it is constructed (HashTableParameter, BatchedFHEPSIServer.hpp:24).  Optional. */
+int piehip_reserve(piehip_handle h, size_t n, uint32_t k, uint32_t e, uint32_t K, uint32_t b, uint32_t E, uint32_t bin_lo,
+                   uint32_t bin_hi);
 /* Only the BatchedFHEHIPPIE constructor (BatchedFHEHIPPIE.cpp:23-82) on the device, for a hash table the caller
  * built itself (the reference's HierarchicalCuckooHashTable): tbl[k][e][K][b][E] = hierarchicalCuckooTable[i][p]
  * .cuckooTable[h][bin][j]; shuffles the bin layers, gathers, draws the masks and encodes. */
 int piehip_load_db_table(piehip_handle h, const uint64_t *tbl, uint32_t k, uint32_t e, uint32_t K, uint32_t b, uint32_t E,
                          uint64_t shuffle_seed, uint64_t mask_seed);
+int piehip_load_db_table_bins(piehip_handle h, const uint64_t *tbl, uint32_t k, uint32_t e, uint32_t K, uint32_t b, uint32_t E,
+                              uint64_t shuffle_seed, uint64_t mask_seed, uint32_t bin_lo, uint32_t bin_hi);
 /* the table built by piehip_build_db, after the bin shuffle: tbl[k][e][K][b][E] (hierarchicalCuckooTable[i][p].cuckooTable) */
 int piehip_get_hash_table(piehip_handle h, uint64_t *tbl);
 /* TabulationHashing::hashWithIndicator for n inputs (host-side; no device needed) */

@@ -30,6 +30,9 @@ SYMBOLS = {
     "piehip_load_db_slots": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, i64p, i64p]),
     "piehip_build_db": (C.c_int, [C.c_void_p, u64p, C.c_size_t] + [C.c_uint32] * 5 + [C.c_uint64] * 4),
     "piehip_load_db_table": (C.c_int, [C.c_void_p, u64p] + [C.c_uint32] * 5 + [C.c_uint64] * 2),
+    "piehip_build_db_bins": (C.c_int, [C.c_void_p, u64p, C.c_size_t] + [C.c_uint32] * 5 + [C.c_uint64] * 4 + [C.c_uint32] * 2),
+    "piehip_load_db_table_bins": (C.c_int, [C.c_void_p, u64p] + [C.c_uint32] * 5 + [C.c_uint64] * 2 + [C.c_uint32] * 2),
+    "piehip_reserve": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_uint32] * 7),
     "piehip_get_hash_table": (C.c_int, [C.c_void_p, u64p]),
     "piehip_tabulation_hash": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, u64p, C.c_size_t, u64p]),
     "piehip_set_index": (C.c_int, [C.c_void_p, u64p]),
@@ -73,7 +76,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = os.environ.get("PIEHIP_LIB", LIB_PATH)  # experiment builds (tools/) may point elsewhere
+        path = LIB_PATH
         if not os.path.exists(path):
             raise RuntimeError(
                 "libpiehip.so is not built (%s). Run nested_hashing_psi_amd.build(); "

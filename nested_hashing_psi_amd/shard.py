@@ -68,3 +68,75 @@ def gather_bins_to(local, b, world, dst=0, out=None, group=None, async_op=False)
         parts = list(out.view(world, bmax, W).unbind(0))
     work = dist.gather(padded, gather_list=parts, dst=dst, group=group, async_op=async_op)
     return (out if rank == dst else None), work
+
+
+class ResultGather:
+    """The sharded server's steady state: run() of query i on this rank's bin layers, then the path's only collective --
+    the gather of the result ciphertexts to the rank that answers the client (reference BatchedFHEPSIServer.cpp:143-152)
+    -- overlapped with run() of query i+1 through two result buffers.
+
+    Stream order (everything is enqueued under `stream`, the stream the PieContext was created on):
+      works[s].wait()        the stream waits until the gather of query i-2 has read buffer s
+      op.run(into=buf[s])    the kernels that write buf[s] wait for the stream (piehip_run_into)
+      op.join()              the stream waits for the run
+      gather(buf[s])         RCCL's stream waits for the stream, i.e. for the run
+    With the `gloo` backend (CPU tests, and the two-process test on one GPU) the results are copied to pinned host
+    buffers on the same stream and the host waits for that copy before the gather.
+    """
+
+    def __init__(self, op, b, b_local, ct_words, device, stream, kind="gather", dst=0, group=None):
+        self.op, self.b, self.dst, self.kind, self.group = op, b, dst, kind, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.stream = stream
+        self.host_staged = dist.get_backend(group) == "gloo"
+        self.bmax = max_bins(b, self.world)
+        self.b_local = b_local
+        assert b_local <= self.bmax
+        self.my_out = [torch.zeros((self.bmax, ct_words), dtype=torch.int64, device=device) for _ in range(2)]
+        cdev = "cpu" if self.host_staged else device
+        self.staged = [torch.zeros((self.bmax, ct_words), dtype=torch.int64).pin_memory() for _ in range(2)] if self.host_staged else None
+        need_all = kind == "all_gather" or self.rank == dst
+        self.gathered = [torch.empty((self.world * self.bmax, ct_words), dtype=torch.int64, device=cdev) if need_all else None
+                         for _ in range(2)]
+        self.works = [None, None]
+        self.i = 0
+
+    def _collective(self, s):
+        src = self.staged[s] if self.host_staged else self.my_out[s]
+        if self.kind == "all_gather":
+            return dist.all_gather_into_tensor(self.gathered[s], src, group=self.group, async_op=True)
+        parts = list(self.gathered[s].view(self.world, self.bmax, -1).unbind(0)) if self.rank == self.dst else None
+        return dist.gather(src, gather_list=parts, dst=self.dst, group=self.group, async_op=True)
+
+    def step(self):
+        s = self.i & 1
+        self.i += 1
+        with torch.cuda.stream(self.stream):
+            if self.works[s] is not None:
+                self.works[s].wait()                 # buffer set s is free again (query i-2 gathered)
+            if self.op is not None and self.b_local:
+                self.op.run(sync=False, into=self.my_out[s].data_ptr())
+                self.op.join()
+            if self.host_staged:
+                self.staged[s].copy_(self.my_out[s], non_blocking=True)
+                self.stream.synchronize()
+            self.works[s] = self._collective(s)
+        return s
+
+    def drain(self):
+        with torch.cuda.stream(self.stream):
+            for w in self.works:
+                if w is not None:
+                    w.wait()
+        self.works = [None, None]
+
+    def rows(self, s):
+        """the b result ciphertexts of buffer set s in bin order (rank dst, or every rank after an all_gather); call after
+        drain() and a stream synchronisation"""
+        g = self.gathered[s]
+        keep = []
+        for r in range(self.world):
+            lo, hi = bin_slice(self.b, r, self.world)
+            keep.append(g[r * self.bmax: r * self.bmax + (hi - lo)])
+        return torch.cat(keep, dim=0)

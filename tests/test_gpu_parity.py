@@ -241,6 +241,19 @@ def test_cpp_facade_runs_reference_call_order(tmp_path):
     assert subprocess.call([exe]) == 0
 
 
+def test_several_handles_and_sharded_facade_in_one_process(tmp_path):
+    """tests/sharded_check.cpp: handles of different rings and moduli side by side; host/ShardedBatchedFHEHIPPIE.hpp over three
+    handles equals the single-handle operator bit for bit"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "nested_hashing_psi_amd")
+    exe = str(tmp_path / "sharded_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(root, "tests", "sharded_check.cpp"),
+                           "-L" + libdir, "-lpiehip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    assert subprocess.call([exe]) == 0
+
+
 @pytest.mark.parametrize("N,L,t,nS,k,e,K,E,b", [
     (4096, 2, T16, 300, 2, 12, 2, 6, 6),
     (2048, 3, T32, 5000, 3, 100, 2, 10, 6),

@@ -63,9 +63,9 @@ def _worker(rank, world, port, b, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("b", [4, 5, 1])
-def test_two_rank_gather_matches_unsharded(b):
-    world = 2
+@pytest.mark.parametrize("world,b", [(2, 4), (2, 5), (2, 1), (4, 14), (4, 3)])
+def test_gather_matches_unsharded(world, b):
+    """two ranks, and four ranks with uneven slices (b = 14 -> 3 + 4 + 3 + 4 bin layers; b = 3 leaves one rank empty)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -77,7 +77,8 @@ def test_two_rank_gather_matches_unsharded(b):
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     slices = sorted(s for _, _, s in res)
-    assert slices[0][0] == 0 and slices[-1][1] == b and slices[0][1] == slices[1][0]
+    assert slices[0][0] == 0 and slices[-1][1] == b and all(slices[i][1] == slices[i + 1][0] for i in range(world - 1))
+    assert max(hi - lo for lo, hi in slices) - min(hi - lo for lo, hi in slices) <= 1
 
 
 def test_bin_slices_partition():
