@@ -1,0 +1,554 @@
+// ntt16_kernel.h -- negacyclic NTT of 2^13-coefficient slices, 16 coefficients per thread (device code, gfx950).
+//
+// The 60-bit Shoup butterfly is bound by the integer ALU (~100 SIMD cycles per wave64 butterfly), and a
+// wave of a transform spends 40-50 % of its life parked at LDS hand-offs, barriers and twiddle loads.  A SIMD issues one VALU
+// instruction every 2 cycles only when at least two of its waves have one ready, so two waves per SIMD (all that 32
+// coefficients per thread leave room for: the LDS image of a slice is 8 bytes per coefficient) keep it about half busy.
+// This kernel halves the per-thread footprint: 512 threads (8 waves) per slice, two slices per CU = 4 waves per SIMD.
+//
+// Forward (Cooley-Tukey, natural order in, bit-reversed out), stage s pairs elements that differ in bit 12 - s:
+//   pass 1  stages 0-2   thread tau holds rows r (stride 1024) of the column pair (2 tau, 2 tau + 1): loaded straight from
+//                        HBM with 16-byte lanes; twiddles depend on r only -> scalar loads
+//   -- LDS transpose, the only workgroup barrier pair of a slice --
+//   pass 2  stages 3-6   wave w, lane l holds e = 1024 w + 64 k + l: twiddles depend on (w, k) only -> scalar loads
+//   -- LDS hand-off inside the wave (a wave's pass-2 elements are its pass-3 and pass-4 elements) --
+//   pass 3  stages 7-10  lane (a, c) holds e = 1024 w + 64 a + 4 k + c; per-lane twiddles from a kernel-ordered table
+//   -- LDS hand-off inside the wave --
+//   pass 4  stages 11-12 lane l holds the 16 contiguous coefficients e = 1024 w + 16 l + k
+// Inverse (Gentleman-Sande) is the mirror image.  HBM traffic: one coalesced read and one coalesced write of the slice.
+// LDS image: element e at e + 2 (e >> 5) (16 bytes of padding per 256): every access pattern above is conflict-free.
+//
+// Lane order.  The evaluation side ends (forward) / starts (inverse) with 16 contiguous coefficients per thread; arrays
+// that never leave the library keep them as the threads hold them: pair j (coefficients 2j, 2j + 1 of the 16) of thread
+// tau at 2 (512 j + tau) -- coalesced 16-byte lanes, no transpose.  Standard (bit-reversed) order costs one more LDS
+// round trip and is offered on the inverse's input side only (the accumulators of stage A arrive in it).
+#pragma once
+#include <vector>
+
+#include "madasm.h"
+#include "params.hpp"
+
+namespace piehip {
+namespace ntt16 {
+
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+static constexpr u32 LOGN = 13;
+static constexpr u32 NS = 1u << LOGN;   // coefficients per slice
+static constexpr u32 T = NS / 16;       // threads per slice
+static constexpr u32 LDS_WORDS = NS + NS / 16;
+static constexpr u32 TWK_PER_SLICE = 8 * 15 * 16 + 8 * 12 * 64;  // kernel-ordered twiddle pairs of passes 3 and 4
+
+__device__ __forceinline__ u32 phi(u32 e) { return e + 2 * (e >> 5); }
+
+struct Tw {  // {w, floor(w 2^63 / q)} split into 32-bit halves
+    u32 wl, wh, sl, sh;
+};
+__device__ __forceinline__ Tw make_tw(u64x2 p)
+{
+    Tw t;
+    t.wl = (u32)p.x, t.wh = (u32)(p.x >> 32), t.sl = (u32)p.y, t.sh = (u32)(p.y >> 32);
+    return t;
+}
+
+// per-modulus constants of the butterflies (wave-uniform: SGPRs)
+struct ModC {
+    u32 nql, nqh;  // 2^64 - q
+    u64 nq4;       // 2^64 - 4q
+    u64 q4p1;      // 4q + 1
+};
+
+// ---- the 60-bit lazy butterfly as hand-scheduled instruction blocks ---------------------------------------------------------
+// Shoup product b w mod q + {0,1,2,3} q with the 63-bit constant ws = floor(w 2^63 / q) (b < 2^63, w < q < 2^60):
+//   quotient estimate  qe = 2 bh sh + ((bh sl + bl sh) >> 31)           3 multiplier ops (bl sl dropped, error <= 3)
+//   remainder          b w + qe (2^64 - q)  mod 2^64                    6 multiplier ops on two accumulation chains
+// (derivation in kernels_ntt_fast.hip).  Why assembly blocks (tools/gen_ntt16_bfly.py writes them): hipcc narrows multiplier
+// ops whose high half is dead to v_mul_lo_u32 (half the rate), lowers conditional subtractions to compare + select chains
+// through VCC (a VALU write of VCC or an SGPR needs two wait states before a VALU may read it on gfx950) and pads every short
+// asm statement with s_nop.  21 (forward) / 23 (inverse) instructions per butterfly, 9 of them on the multiplier, 11 / 13
+// fixed scratch registers at the top of the 128-register budget, no VCC reads (carry-outs are discarded into VCC); conditional
+// subtraction x in [0, 2m) -> [0, m) as t = x - m followed by a select on the sign of t (v_bfi / v_and under an
+// arithmetic-shift mask).
+#define NTT16_S(x) "s"(x)
+#define NTT16_V(x) "v"(x)
+#include "ntt16_bfly.inc"
+
+// forward (Cooley-Tukey): a, b in [0, 8q) -> a' = u + v, b' = u - v + 4q with u = a mod+ 4q in [0, 4q), v = b w in [0, 4q)
+// inverse (Gentleman-Sande): a, b in [0, 4q) -> a' = (a + b) mod+ 4q, b' = (a - b + 4q) w, both in [0, 4q)
+// SC: the twiddles are wave-uniform (SGPR operands)
+template <bool INV, bool SC>
+__device__ __forceinline__ void bfly(u64 &x0, u64 &y0, const Tw &t0, const ModC &m)
+{
+    const u64 a0 = x0, b0 = y0;
+    u64 ao0, bo0;
+    if (INV) {
+        if (SC)
+            NTT16_GS1(NTT16_S);
+        else
+            NTT16_GS1(NTT16_V);
+    } else {
+        if (SC)
+            NTT16_CT1(NTT16_S);
+        else
+            NTT16_CT1(NTT16_V);
+    }
+    x0 = ao0, y0 = bo0;
+}
+// two butterflies (call sites pair them; one block each: see tools/gen_ntt16_bfly.py on why they are not interleaved)
+template <bool INV, bool SC>
+__device__ __forceinline__ void bfly2(u64 &x0, u64 &y0, const Tw &t0, u64 &x1, u64 &y1, const Tw &t1, const ModC &m)
+{
+    bfly<INV, SC>(x0, y0, t0, m);
+    bfly<INV, SC>(x1, y1, t1, m);
+}
+// m-th index in [0, 16) whose bit `d` (a power of two) is clear
+__device__ __forceinline__ constexpr int bfly_lo(int m, int d) { return ((m & ~(d - 1)) << 1) | (m & (d - 1)); }
+
+// DS operations of one wave execute in issue order: a hand-off inside the wave only needs the compiler kept from
+// moving the reads above the writes
+__device__ __forceinline__ void wave_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct Args {
+    u64 *data;            // slices [nitems][NS] (item -> slice through the enumeration below)
+    const u64x2 *twp;     // natural-order {w, w_shoup63} pairs: per modulus [fwd N][inv N]
+    const u64x2 *twk;     // kernel-ordered pairs of passes 3, 4: per modulus [fwd][inv][slices per limb][TWK_PER_SLICE]
+    const DevConsts *dc;
+    u32 N;                // ring dimension (pairs per table)
+    u32 s0;               // log2 slices per limb
+    u32 nitems;           // slices to transform
+    u32 mod_base, mod_count;  // limb i uses modulus mod_base + i % mod_count
+    u32 flags;
+    // forward: the limbs are a compact enumeration of [nb][4][skip_M] without limbs < skip_L of slots 0, 1 (skip_L = 0: off)
+    u32 skip_L, skip_M;
+    // inverse, standard order in: the lane-ordered EVALUATION input of operand-0 polynomials is also written to
+    // copy_out[bin][4][copy_M][N], slots 0, 1, limbs < copy_L (input limbs are [nb][copy_K][2][copy_L])
+    u64 *copy_out;
+    u32 copy_K, copy_L, copy_M;
+};
+enum : u32 {
+    F_STD_IN = 1,    // inverse: EVALUATION input in standard (bit-reversed) order instead of lane order
+    F_LAZY_OUT = 2,  // forward: leave [0, 8q) residues (the consumer reduces anyway)
+    F_FOLDED = 4,    // inverse: the consumer applies the outermost stage and N^-1: hand over [0, 4q) residues as they are
+};
+
+// Host side: the twiddle pairs of passes 3 and 4 of one (modulus, direction) in kernel order, for every slice of a limb.
+// nat: the N natural-order pairs {w, w_shoup63} (index = 2^stage + group).  out: [1 << s0][TWK_PER_SLICE] pairs.
+inline void build_twk_table(const u64 *nat, u32 s0, std::vector<u64> &out)
+{
+    out.assign((size_t)(1u << s0) * TWK_PER_SLICE * 2, 0);
+    for (u32 blk = 0; blk < (1u << s0); blk++) {
+        u64 *o = &out[(size_t)blk * TWK_PER_SLICE * 2];
+        auto put = [&](size_t dst, size_t src) {
+            o[2 * dst] = nat[2 * src];
+            o[2 * dst + 1] = nat[2 * src + 1];
+        };
+        for (u32 w = 0; w < 8; w++) {
+            for (u32 sc = 0; sc < 4; sc++)  // pass 3: stages 7 + sc, 128 << sc local groups
+                for (u32 jj = 0; jj < (1u << sc); jj++)
+                    for (u32 la = 0; la < 16; la++) {
+                        const u32 ml = 128u << sc;
+                        put(((size_t)w * 15 + ((1u << sc) - 1 + jj)) * 16 + la, ((size_t)ml << s0) + (size_t)blk * ml + (((16 * w + la) << sc) + jj));
+                    }
+            for (u32 l = 0; l < 64; l++) {  // pass 4: stages 11 (slots 0..3) and 12 (slots 4..11)
+                for (u32 jj = 0; jj < 4; jj++)
+                    put(8 * 15 * 16 + ((size_t)w * 12 + jj) * 64 + l, ((size_t)2048 << s0) + (size_t)blk * 2048 + 256 * w + 4 * l + jj);
+                for (u32 jj = 0; jj < 8; jj++)
+                    put(8 * 15 * 16 + ((size_t)w * 12 + 4 + jj) * 64 + l, ((size_t)4096 << s0) + (size_t)blk * 4096 + 512 * w + 8 * l + jj);
+            }
+        }
+    }
+}
+// lane-order position p of a slice -> standard (bit-reversed) position
+inline u32 lane_to_std(u32 p)
+{
+    const u32 tau = (p >> 1) % T, j = (p >> 1) / T;
+    return 16 * tau + 2 * j + (p & 1);
+}
+
+// in-kernel cycle stamps are a tooling build (tools/ntt_lab.hip defines NTT16_STAMP before including this file)
+#ifndef NTT16_STAMP
+#define NTT16_STAMP(i)
+#endif
+
+// ---- the four register passes (x[16] in the layout the pass names) ---------------------------------------------------------
+// group index of a stage with ml local groups: global table index (ml << s0) + blk * ml + i
+#define NTT16_TWL(ml, i) tw[(((u32)(ml)) << a.s0) + blk * (u32)(ml) + (i)]
+// LDS addresses are written as (one per-thread base) + (compile-time constant): phi is additive over multiples of 32, and a
+// base the compiler has to keep per row ends up in scratch memory.  Global addresses: uniform row base + one lane offset.
+#define NTT16_FENCE() __builtin_amdgcn_sched_barrier(0)
+#if defined(NTT16_PRIO) && NTT16_PRIO == 2
+#define NTT16_PASS_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define NTT16_PASS_PRIO(p)
+#endif
+
+template <bool INV>
+__global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const u32 tau = threadIdx.x;
+    const u32 w = __builtin_amdgcn_readfirstlane(tau >> 6), l = tau & 63;
+    const u32 la = l >> 2, lc = l & 3;
+    // element -> image position, per layout (phi(e) = e + 2 (e >> 5)):
+    //   pass 1: e = 1024 r + 2 tau          -> p1 + 1088 r            p1 = phi(2 tau)
+    //   pass 2: e = 1024 w + 64 k + l       -> p2 + 68 k              p2 = phi(1024 w + l)
+    //   pass 3: e = 1024 w + 64 a + 4 k + c -> p3 + 4 k + 2 (k >> 3)  p3 = 1088 w + 68 a + c
+    //   pass 4: e = 1024 w + 16 l + k       -> p4 + k                 p4 = phi(1024 w + 16 l)
+    u64 *const p1 = lds + phi(2 * tau);
+    u64 *const p2 = lds + phi(1024 * w + l);
+    u64 *const p3 = lds + 1088 * w + 68 * la + lc;
+    u64 *const p4 = lds + phi(1024 * w + 16 * l);
+    const u32 voff = 2 * tau;  // lane offset (in words) of both global access patterns: rows 1024 r + 2 tau, pairs 2 (512 j + tau)
+    u64 x[16];
+    u64x2 y[8];  // the next slice, loaded while this one is transformed (HBM time and ALU time of a slice are of the same order)
+    // item -> (limb, slice of the limb); forward launches may enumerate [nb][4][skip_M] without the Q limbs of slots 0, 1
+    auto limb_of = [&](u32 it) -> u32 {
+        u32 lb = it >> a.s0;
+        if (!INV && a.skip_L) {
+            const u32 P = a.skip_M - a.skip_L, per = 2 * P + 2 * a.skip_M;
+            const u32 cb = lb / per, r = lb % per;
+            lb = cb * 4 * a.skip_M + (r < 2 * P ? (r / P) * a.skip_M + a.skip_L + r % P : 2 * a.skip_M + (r - 2 * P));
+        }
+        return lb;
+    };
+    auto slice_ptr = [&](u32 it) -> u64 * { return a.data + (((size_t)limb_of(it) << a.s0) + (it & ((1u << a.s0) - 1))) * NS; };
+    // both input layouts are 8 coalesced 16-byte accesses at stride 1024 words: rows of the column pair (COEFFICIENT side,
+    // standard-order EVALUATION side) or pairs 2 (512 j + tau) (lane-ordered EVALUATION side)
+#define NTT16_LOAD_SLICE(it)                                                                     \
+    do {                                                                                         \
+        const u64 *gn_ = slice_ptr(it);                                                          \
+        _Pragma("unroll") for (int r_ = 0; r_ < 8; r_++) y[r_] = *reinterpret_cast<const u64x2 *>(gn_ + 1024 * r_ + voff); \
+    } while (0)
+    if (blockIdx.x < a.nitems) NTT16_LOAD_SLICE(blockIdx.x);
+#ifdef NTT16_PRIO
+    if (NTT16_PRIO == 1 && w >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+
+    for (u32 item = blockIdx.x; item < a.nitems; item += gridDim.x) {
+        const u32 next = item + gridDim.x;
+        const u32 blk = item & ((1u << a.s0) - 1);
+        const u32 limb = limb_of(item);
+        u64 *const g = a.data + (((size_t)limb << a.s0) + blk) * NS;  // uniform
+        const u32 mod = a.mod_base + limb % a.mod_count;
+        const u64 q = a.dc->mod[mod].q;
+        const u64 q2 = 2 * q, q4 = 4 * q;
+        ModC mc;
+        mc.nql = (u32)(0 - q), mc.nqh = (u32)((0 - q) >> 32), mc.nq4 = 0 - q4, mc.q4p1 = q4 + 1;
+        const u64x2 *__restrict__ tw = a.twp + ((size_t)mod * 2 + (INV ? 1 : 0)) * a.N;
+        const u64x2 *__restrict__ twk = a.twk + (((size_t)mod * 2 + (INV ? 1 : 0)) << a.s0) * TWK_PER_SLICE + (size_t)blk * TWK_PER_SLICE;
+        const u64x2 *__restrict__ tw3 = twk + (size_t)w * 15 * 16;                 // [slot 0..14][16 a]
+        const u64x2 *__restrict__ tw4 = twk + 8 * 15 * 16 + (size_t)w * 12 * 64;   // [slot 0..11][64 l]
+        // per-lane twiddles of passes 3 and 4, loaded one stage ahead of their use (named by stage: 7, 8, 9, 10, 11, 12)
+        u64x2 t7[1], t8[2], t9[4], t10[8], t11[4], t12[8];
+#define NTT16_LOAD3(dst, sc)                                                       \
+    _Pragma("unroll") for (int j_ = 0; j_ < (1 << (sc)); j_++) dst[j_] = tw3[16 * ((1 << (sc)) - 1 + j_) + la]
+#define NTT16_LOAD3H(dst, sc, from)                                                \
+    _Pragma("unroll") for (int j_ = (from); j_ < (from) + 4; j_++) dst[j_] = tw3[16 * ((1 << (sc)) - 1 + j_) + la]
+#define NTT16_LOAD4(dst, first, n)                                                 \
+    _Pragma("unroll") for (int j_ = 0; j_ < (n); j_++) dst[j_] = tw4[64 * ((first) + j_) + l]
+
+        if (!INV) {
+            NTT16_STAMP(0);
+            NTT16_PASS_PRIO(3);
+            // ---- pass 1: rows r = 0..7 (bits 12..10) of the column pair -------------------------------------------------
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                x[2 * r] = y[r].x;
+                x[2 * r + 1] = y[r].y;
+            }
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                const int d = 4 >> s;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    if (r & d) continue;
+                    const Tw t = make_tw(NTT16_TWL(1u << s, (u32)r >> (3 - s)));
+                    bfly2<false, true>(x[2 * r], x[2 * (r + d)], t, x[2 * r + 1], x[2 * (r + d) + 1], t, mc);
+                }
+                if (s == 0) {
+                    // The next slice: issued here, one stage after the previous slice's stores (the vector-memory queue is in
+                    // order; loads right behind 64 KiB of stores stall at issue), and ahead of every per-lane twiddle load of
+                    // this slice (passes 1 and 2 take their twiddles through the scalar cache), so that no vmcnt wait for a
+                    // twiddle ends up waiting for HBM.
+                    NTT16_FENCE();
+                    if (next < a.nitems) NTT16_LOAD_SLICE(next);
+                    NTT16_FENCE();
+                }
+            }
+            NTT16_STAMP(1);
+            __syncthreads();  // every wave has finished the previous slice's LDS reads
+            NTT16_STAMP(2);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                u64x2 v;
+                v.x = x[2 * r];
+                v.y = x[2 * r + 1];
+                *reinterpret_cast<u64x2 *>(p1 + 1088 * r) = v;
+            }
+            NTT16_STAMP(3);
+            __syncthreads();
+            NTT16_STAMP(4);
+            // ---- pass 2: e = 1024 w + 64 k + l, stages 3..6 -----------------------------------------------------------------
+            NTT16_PASS_PRIO(2);
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = p2[68 * k];
+#pragma unroll
+            for (int sb = 0; sb < 4; sb++) {
+                const int d = 8 >> sb;
+#pragma unroll
+                for (int mm = 0; mm < 8; mm += 2) {
+                    const int k0 = bfly_lo(mm, d), k1 = bfly_lo(mm + 1, d);
+                    const Tw t0 = make_tw(NTT16_TWL(8u << sb, (w << sb) + ((u32)k0 >> (4 - sb))));
+                    const Tw t1 = make_tw(NTT16_TWL(8u << sb, (w << sb) + ((u32)k1 >> (4 - sb))));
+                    bfly2<false, true>(x[k0], x[k0 + d], t0, x[k1], x[k1 + d], t1, mc);
+                }
+            }
+            // per-lane twiddles from here on, each stage's loaded one stage ahead (the last stages' eight in two halves: with the
+            // next slice in flight the register budget is x 32 + y 32 + twiddles <= 48)
+            NTT16_LOAD3(t7, 0);
+            NTT16_LOAD3(t8, 1);
+#pragma unroll
+            for (int k = 0; k < 16; k++) p2[68 * k] = x[k];
+            NTT16_STAMP(5);
+            wave_sync();
+            // ---- pass 3: e = 1024 w + 64 a + 4 k + c, stages 7..10 -------------------------------------------------------
+            NTT16_PASS_PRIO(1);
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = p3[4 * k + 2 * (k >> 3)];
+            NTT16_LOAD3(t9, 2);
+            NTT16_FENCE();
+            {
+                const Tw t = make_tw(t7[0]);
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) bfly2<false, false>(x[k], x[k + 8], t, x[k + 1], x[k + 9], t, mc);
+            }
+            NTT16_LOAD3H(t10, 3, 0);
+            NTT16_FENCE();
+#pragma unroll
+            for (int mm = 0; mm < 8; mm += 2) {
+                const int k0 = bfly_lo(mm, 4), k1 = bfly_lo(mm + 1, 4);
+                bfly2<false, false>(x[k0], x[k0 + 4], make_tw(t8[k0 >> 3]), x[k1], x[k1 + 4], make_tw(t8[k1 >> 3]), mc);
+            }
+            NTT16_LOAD3H(t10, 3, 4);
+            NTT16_FENCE();
+#pragma unroll
+            for (int mm = 0; mm < 8; mm += 2) {
+                const int k0 = bfly_lo(mm, 2), k1 = bfly_lo(mm + 1, 2);
+                bfly2<false, false>(x[k0], x[k0 + 2], make_tw(t9[k0 >> 2]), x[k1], x[k1 + 2], make_tw(t9[k1 >> 2]), mc);
+            }
+            NTT16_LOAD4(t11, 0, 4);
+            NTT16_FENCE();
+#pragma unroll
+            for (int k = 0; k < 16; k += 4)
+                bfly2<false, false>(x[k], x[k + 1], make_tw(t10[k >> 1]), x[k + 2], x[k + 3], make_tw(t10[(k >> 1) + 1]), mc);
+#pragma unroll
+            for (int k = 0; k < 16; k++) p3[4 * k + 2 * (k >> 3)] = x[k];
+            NTT16_STAMP(6);
+            wave_sync();
+            // ---- pass 4: e = 1024 w + 16 l + k, stages 11, 12 ---------------------------------------------------------------
+            NTT16_PASS_PRIO(0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const u64x2 v = *reinterpret_cast<const u64x2 *>(p4 + 2 * j);
+                x[2 * j] = v.x;
+                x[2 * j + 1] = v.y;
+            }
+            NTT16_LOAD4(t12, 4, 4);
+            NTT16_FENCE();
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {  // stage 11: both butterflies of a group of four share its twiddle
+                const Tw t = make_tw(t11[g4]);
+                bfly2<false, false>(x[4 * g4], x[4 * g4 + 2], t, x[4 * g4 + 1], x[4 * g4 + 3], t, mc);
+                if (g4 == 1) {
+                    NTT16_FENCE();
+                    _Pragma("unroll") for (int j_ = 4; j_ < 8; j_++) t12[j_] = tw4[64 * (4 + j_) + l];
+                    NTT16_FENCE();
+                }
+            }
+            NTT16_FENCE();
+#pragma unroll
+            for (int k = 0; k < 16; k += 4)  // stage 12
+                bfly2<false, false>(x[k], x[k + 1], make_tw(t12[k >> 1]), x[k + 2], x[k + 3], make_tw(t12[(k >> 1) + 1]), mc);
+            NTT16_STAMP(7);
+            // ---- lane-ordered store -------------------------------------------------------------------------------------------
+            const bool lazy = (a.flags & F_LAZY_OUT) != 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                u64 r0 = x[2 * j], r1 = x[2 * j + 1];
+                if (!lazy) {
+                    r0 = r0 >= q4 ? r0 - q4 : r0;
+                    r1 = r1 >= q4 ? r1 - q4 : r1;
+                    r0 = r0 >= q2 ? r0 - q2 : r0;
+                    r1 = r1 >= q2 ? r1 - q2 : r1;
+                    r0 = r0 >= q ? r0 - q : r0;
+                    r1 = r1 >= q ? r1 - q : r1;
+                }
+                u64x2 v;
+                v.x = r0;
+                v.y = r1;
+                *reinterpret_cast<u64x2 *>(g + 2 * T * j + voff) = v;
+            }
+            NTT16_STAMP(8);
+        } else {
+            // ---- input: 16 contiguous coefficients per thread -------------------------------------------------------------
+            NTT16_LOAD4(t12, 4, 8);
+            if (a.flags & F_STD_IN) {
+                // standard order: coalesced rows through LDS
+                __syncthreads();  // previous slice's readers of the image are done
+#pragma unroll
+                for (int r = 0; r < 8; r++) *reinterpret_cast<u64x2 *>(p1 + 1088 * r) = y[r];
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const u64x2 v = *reinterpret_cast<const u64x2 *>(p4 + 2 * j);
+                    x[2 * j] = v.x;
+                    x[2 * j + 1] = v.y;
+                }
+                // operand-0 polynomials keep their EVALUATION form, lane-ordered, as the Q limbs of the QP operand array
+                if (a.copy_out && (limb / (2 * a.copy_L)) % a.copy_K == 0) {
+                    const u32 bin = limb / (2 * a.copy_L * a.copy_K), cc = (limb / a.copy_L) & 1, i = limb % a.copy_L;
+                    u64 *co = a.copy_out + (((((size_t)bin * 4 + cc) * a.copy_M + i) << a.s0) + blk) * NS;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        u64x2 v;
+                        v.x = x[2 * j];
+                        v.y = x[2 * j + 1];
+                        *reinterpret_cast<u64x2 *>(co + 2 * T * j + voff) = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    x[2 * j] = y[j].x;
+                    x[2 * j + 1] = y[j].y;
+                }
+            }
+            NTT16_FENCE();
+            // ---- pass 4': stages 12, 11 ----------------------------------------------------------------------------------------
+            NTT16_LOAD4(t11, 0, 4);
+            NTT16_FENCE();
+#pragma unroll
+            for (int k = 0; k < 16; k += 4)  // stage 12
+                bfly2<true, false>(x[k], x[k + 1], make_tw(t12[k >> 1]), x[k + 2], x[k + 3], make_tw(t12[(k >> 1) + 1]), mc);
+            NTT16_LOAD3(t10, 3);
+            NTT16_FENCE();
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {  // stage 11
+                const Tw t = make_tw(t11[g4]);
+                bfly2<true, false>(x[4 * g4], x[4 * g4 + 2], t, x[4 * g4 + 1], x[4 * g4 + 3], t, mc);
+            }
+            // lane order in: no barrier so far in this slice, and the stores below overwrite the image that the other waves'
+            // pass 1' of the previous slice may still be reading
+            if (!(a.flags & F_STD_IN)) __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                u64x2 v;
+                v.x = x[2 * j];
+                v.y = x[2 * j + 1];
+                *reinterpret_cast<u64x2 *>(p4 + 2 * j) = v;
+            }
+            wave_sync();
+            // ---- pass 3': stages 10..7 -----------------------------------------------------------------------------------------
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = p3[4 * k + 2 * (k >> 3)];
+            NTT16_LOAD3(t9, 2);
+            NTT16_FENCE();
+#pragma unroll
+            for (int k = 0; k < 16; k += 4)
+                bfly2<true, false>(x[k], x[k + 1], make_tw(t10[k >> 1]), x[k + 2], x[k + 3], make_tw(t10[(k >> 1) + 1]), mc);
+            NTT16_LOAD3(t8, 1);
+            NTT16_LOAD3(t7, 0);
+            NTT16_FENCE();
+#pragma unroll
+            for (int mm = 0; mm < 8; mm += 2) {
+                const int k0 = bfly_lo(mm, 2), k1 = bfly_lo(mm + 1, 2);
+                bfly2<true, false>(x[k0], x[k0 + 2], make_tw(t9[k0 >> 2]), x[k1], x[k1 + 2], make_tw(t9[k1 >> 2]), mc);
+            }
+            NTT16_FENCE();
+#pragma unroll
+            for (int mm = 0; mm < 8; mm += 2) {
+                const int k0 = bfly_lo(mm, 4), k1 = bfly_lo(mm + 1, 4);
+                bfly2<true, false>(x[k0], x[k0 + 4], make_tw(t8[k0 >> 3]), x[k1], x[k1 + 4], make_tw(t8[k1 >> 3]), mc);
+            }
+            {
+                const Tw t = make_tw(t7[0]);
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) bfly2<true, false>(x[k], x[k + 8], t, x[k + 1], x[k + 9], t, mc);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) p3[4 * k + 2 * (k >> 3)] = x[k];
+            wave_sync();
+            // ---- pass 2': stages 6..3 ------------------------------------------------------------------------------------------
+            // the next slice, issued behind the last per-lane twiddle load of this one; it has passes 2' and 1' (scalar-cache
+            // twiddles) to arrive
+            NTT16_FENCE();
+            if (next < a.nitems) NTT16_LOAD_SLICE(next);
+            NTT16_FENCE();
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = p2[68 * k];
+#pragma unroll
+            for (int sb = 3; sb >= 0; sb--) {
+                const int d = 8 >> sb;
+#pragma unroll
+                for (int mm = 0; mm < 8; mm += 2) {
+                    const int k0 = bfly_lo(mm, d), k1 = bfly_lo(mm + 1, d);
+                    const Tw t0 = make_tw(NTT16_TWL(8u << sb, (w << sb) + ((u32)k0 >> (4 - sb))));
+                    const Tw t1 = make_tw(NTT16_TWL(8u << sb, (w << sb) + ((u32)k1 >> (4 - sb))));
+                    bfly2<true, true>(x[k0], x[k0 + d], t0, x[k1], x[k1 + d], t1, mc);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) p2[68 * k] = x[k];
+            __syncthreads();
+            // ---- pass 1': stages 2..0, stored straight to HBM ------------------------------------------------------------------
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const u64x2 v = *reinterpret_cast<const u64x2 *>(p1 + 1088 * r);
+                x[2 * r] = v.x;
+                x[2 * r + 1] = v.y;
+            }
+#pragma unroll
+            for (int s = 2; s >= 0; s--) {
+                const int d = 4 >> s;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    if (r & d) continue;
+                    const Tw t = make_tw(NTT16_TWL(1u << s, (u32)r >> (3 - s)));
+                    bfly2<true, true>(x[2 * r], x[2 * (r + d)], t, x[2 * r + 1], x[2 * (r + d) + 1], t, mc);
+                }
+            }
+            const Mod &m = a.dc->mod[mod];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                u64x2 v;
+                if (a.flags & F_FOLDED) {
+                    v.x = x[2 * r];
+                    v.y = x[2 * r + 1];
+                } else if (a.s0 == 0) {
+                    v.x = mul_shoup(x[2 * r], m.n_inv, m.n_inv_sh, q);
+                    v.y = mul_shoup(x[2 * r + 1], m.n_inv, m.n_inv_sh, q);
+                } else {  // split transform: the global-memory stages expect canonical residues
+                    u64 r0 = x[2 * r], r1 = x[2 * r + 1];
+                    r0 = r0 >= q2 ? r0 - q2 : r0;
+                    r1 = r1 >= q2 ? r1 - q2 : r1;
+                    v.x = r0 >= q ? r0 - q : r0;
+                    v.y = r1 >= q ? r1 - q : r1;
+                }
+                *reinterpret_cast<u64x2 *>(g + 1024 * r + voff) = v;
+            }
+        }
+    }
+}
+#undef NTT16_LOAD3
+#undef NTT16_LOAD3H
+#undef NTT16_LOAD_SLICE
+#undef NTT16_LOAD4
+#undef NTT16_FENCE
+#undef NTT16_TWL
+
+}  // namespace ntt16
+}  // namespace piehip

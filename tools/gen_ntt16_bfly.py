@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Generates nested_hashing_psi_amd/csrc/ntt16_bfly.inc: the 60-bit lazy NTT butterflies of ntt16_kernel.h as hand-scheduled
+gfx950 instruction blocks (the generator can interleave NB independent butterflies per block; NB = 1 is what ships).
+
+Issue costs on gfx950 (tools/microbench_ops.hip, cycles per wave64 instruction per SIMD with 2+ waves): every VOP3 instruction --
+v_mad_u64_u32, v_lshl_add_u64, v_lshrrev_b64, v_bfi_b32, v_mul_lo/hi_u32 alike -- 4.1-4.3; 32-bit VOP1/VOP2 2.0-2.5; a wave
+alone on its SIMD 4+ for everything.  A forward block is 9 + 7 VOP3 and 5 VOP2 instructions = ~78 cycles.
+
+    python tools/gen_ntt16_bfly.py          (rewrites the .inc; the output is committed)
+
+Register use of stream i: n = 11 (forward) or 13 (inverse) fixed VGPRs v[128 - n (i + 1) .. 128 - n i) (an asm operand cannot name the halves of a
+64-bit pair, so every temporary whose halves are needed lives in a named register; all are in the clobber list).
+"""
+import os
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nested_hashing_psi_amd", "csrc", "ntt16_bfly.inc")
+
+
+NREG = {False: 11, True: 13}  # fixed VGPRs per stream: forward (CT), inverse (GS)
+
+
+class Regs:
+    """Fixed registers of stream i.  Lifetimes allow these overlays (see the instruction lists):
+    both: M over X (the mask is computed after the last use of 2 bh), U over T (the select / t writes in place)
+    CT:   N over CR (cr is dead once qe exists), T6 over QE (computed after the last use of qe)
+    GS:   N and the masked 4q over CR, the early a + 4q + 1 over QE (dead before qe is written), D extra"""
+    def __init__(self, i, gs):
+        n = NREG[gs]
+        self.n = n
+        self.base = 128 - n * (i + 1)
+        b = self.base
+        self.X = b           # 2 bh
+        self.M = b           # sign mask
+        self.T = b + 1       # t = x - 4q
+        self.U = self.T      # CT: u (in place); GS: s, then t in place
+        self.CR = b + 3      # m1 / cr / cr >> 31
+        self.N = self.CR     # ~v (CT, after qe) / ~b (GS, before m1)
+        self.QE = b + 5
+        self.T6 = self.QE    # CT: u + 4q + 1 (after the last use of qe); GS: a + 4q + 1 (before qe)
+        self.ACC = b + 7     # acc, then v
+        self.C = b + 9
+        self.D = b + 11      # GS only: d = a - b + 4q
+
+    def all(self):
+        return range(self.base, self.base + self.n)
+
+
+def p(r):
+    return "v[%d:%d]" % (r, r + 1)
+
+
+def v(r):
+    return "v%d" % r
+
+
+def ct_stream(i):
+    r = Regs(i, False)
+    o = lambda name: "%%[%s%d]" % (name, i)
+    bl, bh = o("bl"), o("bh")
+    return [
+        "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.CR), bl, o("sh")),                  # m1 = bl sh
+        "v_lshl_add_u64 %s, %s, 0, %%[nq4]" % (p(r.T), o("a")),                       # t = a - 4q
+        "v_lshlrev_b32 %s, 1, %s" % (v(r.X), bh),                                     # 2 bh
+        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.CR), bh, o("sl"), p(r.CR)),        # cr = bh sl + m1
+        "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.ACC), bl, o("wl")),                 # acc = bl wl
+        "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.C), bl, o("wh")),                   # c = bl wh
+        "v_lshrrev_b64 %s, 31, %s" % (p(r.CR), p(r.CR)),
+        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.C), bh, o("wl"), p(r.C)),          # c += bh wl
+        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.QE), v(r.X), o("sh"), p(r.CR)),    # qe = 2 bh sh + (cr >> 31)
+        "v_ashrrev_i32 %s, 31, %s" % (v(r.M), v(r.T + 1)),                            # all ones iff t < 0   (over 2 bh)
+        "v_bfi_b32 %s, %s, %s, %s" % (v(r.U), v(r.M), o("al"), v(r.T)),               # u = t < 0 ? a : t   (in place)
+        "v_bfi_b32 %s, %s, %s, %s" % (v(r.U + 1), v(r.M), o("ah"), v(r.T + 1)),
+        "v_mad_u64_u32 %s, vcc, %s, %%[nql], %s" % (p(r.ACC), v(r.QE), p(r.ACC)),     # acc += qe_lo nq_lo
+        "v_mad_u64_u32 %s, vcc, %s, %%[nqh], %s" % (p(r.C), v(r.QE), p(r.C)),         # c += qe_lo nq_hi
+        "v_mad_u64_u32 %s, vcc, %s, %%[nql], %s" % (p(r.C), v(r.QE + 1), p(r.C)),     # c += qe_hi nq_lo
+        "v_lshl_add_u64 %s, %s, 0, %%[q4p1]" % (p(r.T6), p(r.U)),                     # u + 4q + 1   (over qe)
+        "v_not_b32 %s, %s" % (v(r.N), v(r.ACC)),
+        "v_add_u32 %s, %s, %s" % (v(r.ACC + 1), v(r.ACC + 1), v(r.C)),                # v = acc + (c << 32)
+        "v_not_b32 %s, %s" % (v(r.N + 1), v(r.ACC + 1)),
+        "v_lshl_add_u64 %s, %s, 0, %s" % (o("ao"), p(r.U), p(r.ACC)),                 # a' = u + v
+        "v_lshl_add_u64 %s, %s, 0, %s" % (o("bo"), p(r.T6), p(r.N)),                  # b' = u + 4q + 1 + ~v
+    ]
+
+
+def gs_stream(i):
+    r = Regs(i, True)
+    o = lambda name: "%%[%s%d]" % (name, i)
+    dl, dh = v(r.D), v(r.D + 1)
+    return [
+        "v_not_b32 %s, %s" % (v(r.N), o("bl")),
+        "v_not_b32 %s, %s" % (v(r.N + 1), o("bh")),
+        "v_lshl_add_u64 %s, %s, 0, %%[q4p1]" % (p(r.T6), o("a")),                     # a + 4q + 1   (over qe, dead here)
+        "v_lshl_add_u64 %s, %s, 0, %s" % (p(r.U), o("a"), o("b")),                    # s = a + b
+        "v_lshl_add_u64 %s, %s, 0, %s" % (p(r.D), p(r.T6), p(r.N)),                   # d = a - b + 4q
+        "v_lshl_add_u64 %s, %s, 0, %%[nq4]" % (p(r.T), p(r.U)),                       # t = s - 4q   (in place)
+        "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.CR), dl, o("sh")),
+        "v_lshlrev_b32 %s, 1, %s" % (v(r.X), dh),
+        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.CR), dh, o("sl"), p(r.CR)),
+        "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.ACC), dl, o("wl")),
+        "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.C), dl, o("wh")),
+        "v_lshrrev_b64 %s, 31, %s" % (p(r.CR), p(r.CR)),
+        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.C), dh, o("wl"), p(r.C)),
+        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.QE), v(r.X), o("sh"), p(r.CR)),
+        "v_ashrrev_i32 %s, 31, %s" % (v(r.M), v(r.T + 1)),
+        "v_and_b32 %s, %%[q4l], %s" % (v(r.CR), v(r.M)),                              # 4q under the mask   (over cr, dead here)
+        "v_and_b32 %s, %%[q4h], %s" % (v(r.CR + 1), v(r.M)),
+        "v_mad_u64_u32 %s, vcc, %s, %%[nql], %s" % (p(r.ACC), v(r.QE), p(r.ACC)),
+        "v_lshl_add_u64 %s, %s, 0, %s" % (o("ao"), p(r.T), p(r.CR)),                  # a' = t < 0 ? s : t
+        "v_mad_u64_u32 %s, vcc, %s, %%[nqh], %s" % (p(r.C), v(r.QE), p(r.C)),
+        "v_mad_u64_u32 %s, vcc, %s, %%[nql], %s" % (p(r.C), v(r.QE + 1), p(r.C)),
+        "v_add_u32 %s, %s, %s" % (v(r.ACC + 1), v(r.ACC + 1), v(r.C)),
+        "v_lshl_add_u64 %s, %s, 0, 0" % (o("bo"), p(r.ACC)),                          # b' = d w
+    ]
+
+
+def interleave(streams):
+    out = []
+    for k in range(max(len(s) for s in streams)):
+        for s in streams:
+            if k < len(s):
+                out.append(s[k])
+    return out
+
+
+def emit(name, gs, nb):
+    lines = interleave([(gs_stream if gs else ct_stream)(i) for i in range(nb)])
+    body = " \\\n".join('        "%s\\n\\t"' % ln for ln in lines)
+    # no early-clobber: every input is read before the first output is written (checked below), so outputs may reuse input registers
+    first_out = min(k for k, ln in enumerate(lines) if "%[ao" in ln or "%[bo" in ln)
+    vgpr_inputs = ["%%[%s%d]" % (nm, i) for nm in ("a", "b", "al", "ah", "bl", "bh", "wl", "wh", "sl", "sh") for i in range(nb)]
+    for ln in lines[first_out + 1:]:
+        assert not any(op in ln for op in vgpr_inputs), "input read after an output was written: " + ln
+    outs = ", ".join('[ao%d] "=v"(ao%d), [bo%d] "=v"(bo%d)' % (i, i, i, i) for i in range(nb))
+    ins = []
+    for i in range(nb):
+        if gs:
+            ins.append('[a%d] "v"(a%d), [b%d] "v"(b%d), [bl%d] "v"((u32)b%d), [bh%d] "v"((u32)(b%d >> 32))' % ((i,) * 8))
+        else:
+            ins.append('[a%d] "v"(a%d), [al%d] "v"((u32)a%d), [ah%d] "v"((u32)(a%d >> 32)), [bl%d] "v"((u32)b%d), [bh%d] "v"((u32)(b%d >> 32))'
+                       % ((i,) * 10))
+        ins.append('[wl%d] TWC(t%d.wl), [wh%d] TWC(t%d.wh), [sl%d] TWC(t%d.sl), [sh%d] TWC(t%d.sh)' % ((i,) * 8))
+    ins.append('[nql] "s"(m.nql), [nqh] "s"(m.nqh), [nq4] "s"(m.nq4), [q4p1] "s"(m.q4p1)')
+    if gs:
+        ins.append('[q4l] "s"((u32)(m.q4p1 - 1)), [q4h] "s"((u32)((m.q4p1 - 1) >> 32))')
+    clob = ['"vcc"'] + ['"v%d"' % x for i in range(nb) for x in Regs(i, gs).all()]
+    return ("#define %s(TWC) \\\n    asm( \\\n%s \\\n        : %s \\\n        : %s \\\n        : %s)\n"
+            % (name, body, outs, ", \\\n          ".join(ins), ", ".join(clob)))
+
+
+def main():
+    text = ("// ntt16_bfly.inc -- GENERATED by tools/gen_ntt16_bfly.py; do not edit.  See that script and ntt16_kernel.h.\n"
+            "// NTT16_{CT,GS}1(TWC): one butterfly on (a0, b0, t0) -> (ao0, bo0);\n"
+            "// TWC = NTT16_S (wave-uniform twiddles, SGPR operands) or NTT16_V (per-lane twiddles); m = ModC.\n")
+    # one butterfly per block: measured, a wave issues at most every other VALU slot whatever its instruction-level parallelism
+    # (interleaving two butterflies per block changed nothing but the register count), so parallelism comes from waves
+    for nb in (1,):
+        text += emit("NTT16_CT%d" % nb, False, nb) + emit("NTT16_GS%d" % nb, True, nb)
+    with open(OUT, "w") as f:
+        f.write(text)
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()
