@@ -29,6 +29,8 @@ struct NttPlan {
     const u64 *twp;       // interleaved {w, w_shoup} pairs: per modulus [fwd N pairs][inv N pairs]
     const u64 *twc;       // pass-C twiddles in kernel order: per modulus [fwd][inv], see build_twc_table
     const u64 *twc_fold;  // the same for the folded configuration (two half-size slices per limb), or null
+    const u64 *twk16 = nullptr;       // ntt16_kernel.h: kernel-ordered pairs of passes 3, 4, one 2^13 slice per limb (ring 2^13), or null
+    const u64 *twk16_fold = nullptr;  // ... two folded 2^13 slices per limb (ring 2^14), or null
     const DevConsts *dc;  // device pointer
     u32 N, logN;
     u32 num_cus;
@@ -52,6 +54,17 @@ struct NttExtra {
     bool lazy_out = false;  // forward, lane order: leave the residues in [0, 8q) (the consumer reduces anyway)
     bool folded = false;    // set by launch_ntt(.., folded): inverse transforms then hand over unnormalised [0, 4q) residues
 };
+// The 16-coefficients-per-thread kernel (ntt16_kernel.h, kernels_ntt16.hip) for 2^13-coefficient slices: every transform whose
+// EVALUATION side is in lane order, and every inverse transform.  Its lane order differs from the 32-coefficient kernel's:
+// a context uses one of the two for all lane-ordered arrays (ntt16_applies).  Returns false when it does not apply.
+void build_twk16_table(const u64 *nat_pairs, u32 s0, std::vector<u64> &out);
+void ntt16_sigma_inverse_map(u32 logN, u32 s0, std::vector<u32> &map);
+bool launch_ntt16(const NttPlan &pl, bool folded, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, bool sigma,
+                  hipStream_t st, const NttExtra *ex);
+inline bool ntt16_applies(const NttPlan &pl, bool folded)
+{
+    return !pl.force_generic && pl.twp && (folded ? (pl.twk16_fold && pl.logN == 14) : (pl.twk16 && pl.logN == 13));
+}
 bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
                      u32 mod_count, bool inverse, bool sigma, u32 num_cus, hipStream_t st, const u64 *lift_src = nullptr,
                      u32 lift_L = 0, u32 sigma_split = 0, const NttExtra *ex = nullptr);
@@ -106,10 +119,11 @@ void launch_digits(const DevConsts *dc, u32 N, u32 L, const u64 *d2, size_t stri
 // out[bin][c][j] = (d01[bin][c][j] + sum_i dig[bin][i][j] (.) key[i][c][j]) (.) mask[bin][j]   (mask may be null)
 // out_map (may be null): coefficient n of the result is written to position out_map[n] (lane order -> standard)
 // key_group > 1: ciphertext `bin` uses key + (bin % key_group) * key_stride (EvalMerge: one rotation key per position)
-// sigma_T != 0: out_map is ntt_sigma_inverse_map of a transform with sigma_T threads per slice; stores go through an LDS tile
+// sigma_T != 0: out_map is the lane order of a transform with sigma_T threads per slice and sigma_kp coefficient pairs per thread
+// (16: kernels_ntt_fast.hip, 8: ntt16_kernel.h); stores then go through an LDS tile
 void launch_relin_mac(const DevConsts *dc, u32 N, u32 L, const u64 *d01, size_t stride01, const u64 *dig, const u64 *key,
                       const u64 *mask, u64 *out, u32 nb, hipStream_t st, const u32 *out_map = nullptr, size_t key_stride = 0,
-                      u32 key_group = 1, u32 sigma_T = 0);
+                      u32 key_group = 1, u32 sigma_T = 0, u32 sigma_kp = 16);
 // rotation-based PIE (FHEHIPPIE.cpp:61-77), see kernels_pie.hip
 void launch_bcast_mul_plain(const DevConsts *dc, u32 N, u32 L, const u64 *x, size_t xs, u32 group, const u64 *pt, size_t ps_outer,
                             size_t ps_inner, u64 *out, u32 nct, hipStream_t st);

@@ -143,6 +143,7 @@ u32 ntt_fast_s0(u32 logN)
 bool launch_ntt_digits(const NttPlan &pl, const u64 *d2, u64 *dig, u32 nb, u32 L, bool sigma, bool folded_layout, hipStream_t st)
 {
     if (pl.force_generic || !pl.twp || !pl.twc || ntt_fast_s0(pl.logN) != 0) return false;
+    if (sigma && ntt16_applies(pl, folded_layout)) return false;  // the lane order is the 16-coefficient kernel's: digits kernel + its transform
     return launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, 0, dig, nb * L * L, 0, L, false, sigma, pl.num_cus, st, d2, L,
                            (sigma && folded_layout) ? 1u : 0u);
 }
@@ -150,6 +151,7 @@ bool launch_ntt_digits(const NttPlan &pl, const u64 *d2, u64 *dig, u32 nb, u32 L
 bool ntt_supports_extra(const NttPlan &pl, bool folded)
 {
     if (pl.force_generic || !pl.twp) return false;
+    if (ntt16_applies(pl, folded)) return true;
     if (folded) return pl.twc_fold != nullptr;
     return pl.twc != nullptr && ntt_fast_s0(pl.logN) == 0;
 }
@@ -158,6 +160,7 @@ void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_
                 bool folded, const NttExtra *ex)
 {
     if (!nlimbs) return;
+    if (ntt16_applies(pl, folded) && launch_ntt16(pl, folded, data, nlimbs, mod_base, mod_count, inverse, sigma, st, ex)) return;
     if (folded) {  // two half-size slices per limb, outer stage done by the neighbouring kernels
         NttExtra exf;
         if (ex) exf = *ex;

@@ -1,0 +1,65 @@
+// kernels_ntt16.hip -- launch side of the 16-coefficients-per-thread NTT (ntt16_kernel.h) for slices of 2^13 coefficients:
+// ring 2^13 as one slice per limb, ring 2^14 as two slices with the outermost stage folded into the neighbouring kernels.
+// Replaces DCRTPoly::SetFormat under EvalMult(ct, ct) (reference BatchedFHEHIPPIE.cpp:123).
+#include "kernels.hpp"
+#include "ntt16_kernel.h"
+
+namespace piehip {
+
+void build_twk16_table(const u64 *nat_pairs, u32 s0, std::vector<u64> &out) { ntt16::build_twk_table(nat_pairs, s0, out); }
+
+void ntt16_sigma_inverse_map(u32 logN, u32 s0, std::vector<u32> &map)
+{
+    const u32 N = 1u << logN, n = N >> s0;
+    map.resize(N);
+    for (u32 p = 0; p < N; p++) map[p] = (p / n) * n + ntt16::lane_to_std(p % n);
+}
+
+bool launch_ntt16(const NttPlan &pl, bool folded, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, bool sigma,
+                  hipStream_t st, const NttExtra *ex)
+{
+    const u64 *twk = folded ? pl.twk16_fold : pl.twk16;
+    const u32 s0 = folded ? 1u : 0u;
+    if (pl.force_generic || !twk || !pl.twp || pl.logN - s0 != ntt16::LOGN) return false;
+    if (!inverse && !sigma) return false;  // standard-order output is the 32-coefficient kernel's
+    ntt16::Args a;
+    a.data = data;
+    a.twp = reinterpret_cast<const ntt16::u64x2 *>(pl.twp);
+    a.twk = reinterpret_cast<const ntt16::u64x2 *>(twk);
+    a.dc = pl.dc;
+    a.N = pl.N;
+    a.s0 = s0;
+    a.nitems = nlimbs << s0;
+    a.mod_base = mod_base;
+    a.mod_count = mod_count;
+    a.flags = 0;
+    if (inverse && !sigma) a.flags |= ntt16::F_STD_IN;
+    if (inverse && folded) a.flags |= ntt16::F_FOLDED;
+    if (!inverse && ex && ex->lazy_out) a.flags |= ntt16::F_LAZY_OUT;
+    a.skip_L = (ex && !inverse) ? ex->skip_L : 0;
+    a.skip_M = ex ? ex->skip_M : 0;
+    a.copy_out = (ex && inverse && !sigma) ? ex->copy_out : nullptr;
+    a.copy_K = ex ? ex->copy_K : 1;
+    a.copy_L = ex ? ex->copy_L : 1;
+    a.copy_M = ex ? ex->copy_M : 1;
+    a.stagger_from = ~0u;
+    a.stagger_sleeps = 0;
+    constexpr size_t lds = (size_t)ntt16::LDS_WORDS * sizeof(u64);
+    static PerDeviceOnce attr[2];
+    if (attr[inverse ? 1 : 0].first_on_current_device()) {
+        if (inverse)
+            (void)hipFuncSetAttribute((const void *)ntt16::ntt16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else
+            (void)hipFuncSetAttribute((const void *)ntt16::ntt16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    // two resident workgroups per CU (68 KiB of LDS, 128 VGPRs each); persistent beyond that
+    const u32 slots = 2 * pl.num_cus;
+    const u32 grid = a.nitems < slots ? a.nitems : slots;
+    if (inverse)
+        hipLaunchKernelGGL(ntt16::ntt16_kernel<true>, dim3(grid), dim3(ntt16::T), lds, st, a);
+    else
+        hipLaunchKernelGGL(ntt16::ntt16_kernel<false>, dim3(grid), dim3(ntt16::T), lds, st, a);
+    return true;
+}
+
+}  // namespace piehip

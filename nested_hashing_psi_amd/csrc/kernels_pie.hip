@@ -572,25 +572,28 @@ void launch_digits(const DevConsts *dc, u32 N, u32 L, const u64 *d2, size_t stri
 
 // One thread: two adjacent coefficients (16-byte lanes) of one (bin, limb j), both ciphertext components, so a
 // digit is loaded once for its two key products.  out_map (lane order -> standard) keeps pairs adjacent.
-// TILE (lane-ordered inputs of the register-blocked transform, T = threads per slice): a block takes the 16 x 16 pairs
-// (thread tau0..tau0+15 of the transform) x (pair k = 0..15), i.e. sixteen 256-byte runs of the lane order, and hands the
-// results through LDS so that they leave as one contiguous 4 KiB run of the standard order (pair 16 tau + k); with the
-// plain out_map scatter every 16-byte store lands in its own 256-byte stretch.
-template <bool MAD, bool TILE>
+// KP > 0 (lane-ordered inputs of a register-blocked transform with T threads per slice and KP coefficient pairs per thread:
+// pair k of thread tau sits at k T + tau and belongs at KP tau + k): a block takes the (256 / KP) x KP pairs of threads
+// tau0 .. tau0 + 256 / KP - 1, i.e. KP contiguous runs of the lane order, and hands the results through LDS so that they leave
+// as one contiguous 4 KiB run of the standard order; with the plain out_map scatter every 16-byte store lands in its own
+// stretch.  KP = 16: kernels_ntt_fast.hip (32 coefficients per thread), KP = 8: ntt16_kernel.h.
+template <bool MAD, int KP>
 __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, const u64 *__restrict__ d01,
                                                         size_t stride01, const u64 *__restrict__ dig,
                                                         const u64 *__restrict__ key0, const u64 *__restrict__ mask,
                                                         u64 *__restrict__ out, const u32 *__restrict__ out_map,
                                                         size_t key_stride, u32 key_group, u32 T)
 {
+    constexpr bool TILE = KP > 0;
+    constexpr u32 TT = TILE ? TPB / (KP ? KP : 1) : 1;  // threads of the transform per tile
     __shared__ u64x2 s_tile[TILE ? 2 : 1][TILE ? TPB : 1];
     u32 n = 2 * (blockIdx.x * TPB + threadIdx.x);
     u32 std_pair = 0;  // TILE: first standard-order pair of this block's tile
     if (TILE) {
-        const u32 tiles = T / 16, slice = blockIdx.x / tiles, tau0 = (blockIdx.x % tiles) * 16;
-        const u32 k = threadIdx.x >> 4, tt = threadIdx.x & 15;
-        n = 2 * (slice * 16 * T + k * T + tau0 + tt);
-        std_pair = slice * 16 * T + 16 * tau0;
+        const u32 tiles = T / TT, slice = blockIdx.x / tiles, tau0 = (blockIdx.x % tiles) * TT;
+        const u32 k = threadIdx.x / TT, tt = threadIdx.x % TT;
+        n = 2 * (slice * KP * T + k * T + tau0 + tt);
+        std_pair = slice * KP * T + KP * tau0;
     }
     if (n >= N) return;
     const u32 j = blockIdx.y, bin = blockIdx.z;
@@ -646,7 +649,7 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restr
             r.y = mulmod(r.y, mk.y, m);
         }
         if (TILE)
-            s_tile[c][16 * (threadIdx.x & 15) + (threadIdx.x >> 4)] = r;  // standard offset inside the tile: 16 (tau - tau0) + k
+            s_tile[c][KP * (threadIdx.x % TT) + threadIdx.x / TT] = r;  // standard offset inside the tile: KP (tau - tau0) + k
         else
             *reinterpret_cast<u64x2 *>(out + ((size_t)bin * 2 + c) * LN + (size_t)j * N + po) = r;
     }
@@ -659,19 +662,21 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restr
 }
 void launch_relin_mac(const DevConsts *dc, u32 N, u32 L, const u64 *d01, size_t stride01, const u64 *dig, const u64 *key,
                       const u64 *mask, u64 *out, u32 nb, hipStream_t st, const u32 *out_map, size_t key_stride, u32 key_group,
-                      u32 sigma_T)
+                      u32 sigma_T, u32 sigma_kp)
 {
     dim3 grid((N / 2 + TPB - 1) / TPB, L, nb);
     if (!key_group) key_group = 1;
-    // sigma_T: out_map is the lane order of the register-blocked transform with sigma_T threads per slice
-    const bool tile = out_map && sigma_T >= 16 && sigma_T % 16 == 0 && (N / 2) % TPB == 0;
-#define RM(M_, T_)                                                                                                              \
-    hipLaunchKernelGGL((relin_mac_kernel<M_, T_>), grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map, \
+    // sigma_T: out_map is the lane order of a register-blocked transform with sigma_T threads per slice, sigma_kp pairs per thread
+    const bool tile = out_map && (sigma_kp == 16 || sigma_kp == 8) && sigma_T >= TPB / sigma_kp && sigma_T % (TPB / sigma_kp) == 0 &&
+                      (N / 2) % TPB == 0;
+    const int kp = tile ? (int)sigma_kp : 0;
+#define RM(M_, K_)                                                                                                              \
+    hipLaunchKernelGGL((relin_mac_kernel<M_, K_>), grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map, \
                        key_stride, key_group, sigma_T)
     if (g_small_moduli) {
-        if (tile) RM(true, true); else RM(true, false);
+        if (kp == 16) RM(true, 16); else if (kp == 8) RM(true, 8); else RM(true, 0);
     } else {
-        if (tile) RM(false, true); else RM(false, false);
+        if (kp == 16) RM(false, 16); else if (kp == 8) RM(false, 8); else RM(false, 0);
     }
 #undef RM
 }

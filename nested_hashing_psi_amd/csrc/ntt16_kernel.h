@@ -128,6 +128,8 @@ struct Args {
     // copy_out[bin][4][copy_M][N], slots 0, 1, limbs < copy_L (input limbs are [nb][copy_K][2][copy_L])
     u64 *copy_out;
     u32 copy_K, copy_L, copy_M;
+    // workgroups from this index on begin stagger_sleeps x ~1000 cycles late (see the kernel); stagger_from >= grid: off
+    u32 stagger_from, stagger_sleeps;
 };
 enum : u32 {
     F_STD_IN = 1,    // inverse: EVALUATION input in standard (bit-reversed) order instead of lane order
@@ -204,7 +206,6 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
     u64 *const p4 = lds + phi(1024 * w + 16 * l);
     const u32 voff = 2 * tau;  // lane offset (in words) of both global access patterns: rows 1024 r + 2 tau, pairs 2 (512 j + tau)
     u64 x[16];
-    u64x2 y[8];  // the next slice, loaded while this one is transformed (HBM time and ALU time of a slice are of the same order)
     // item -> (limb, slice of the limb); forward launches may enumerate [nb][4][skip_M] without the Q limbs of slots 0, 1
     auto limb_of = [&](u32 it) -> u32 {
         u32 lb = it >> a.s0;
@@ -215,21 +216,18 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
         }
         return lb;
     };
-    auto slice_ptr = [&](u32 it) -> u64 * { return a.data + (((size_t)limb_of(it) << a.s0) + (it & ((1u << a.s0) - 1))) * NS; };
-    // both input layouts are 8 coalesced 16-byte accesses at stride 1024 words: rows of the column pair (COEFFICIENT side,
-    // standard-order EVALUATION side) or pairs 2 (512 j + tau) (lane-ordered EVALUATION side)
-#define NTT16_LOAD_SLICE(it)                                                                     \
-    do {                                                                                         \
-        const u64 *gn_ = slice_ptr(it);                                                          \
-        _Pragma("unroll") for (int r_ = 0; r_ < 8; r_++) y[r_] = *reinterpret_cast<const u64x2 *>(gn_ + 1024 * r_ + voff); \
-    } while (0)
-    if (blockIdx.x < a.nitems) NTT16_LOAD_SLICE(blockIdx.x);
+    // Workgroups that share a CU with an earlier one start a little late: every workgroup of a launch begins with 64 KiB of
+    // loads, and issued together the two streams of a CU interleave and complete together -- a phase in which the whole chip
+    // waits for HBM and no ALU has work, followed by one in which HBM idles.  Behind a ~1 us head start the first stream is
+    // served first, its workgroup computes while the second one loads, and the stores at the end stagger the same way.
+    if (blockIdx.x >= a.stagger_from) {
+        for (u32 i = 0; i < a.stagger_sleeps; i++) __builtin_amdgcn_s_sleep(16);
+    }
 #ifdef NTT16_PRIO
     if (NTT16_PRIO == 1 && w >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
 
     for (u32 item = blockIdx.x; item < a.nitems; item += gridDim.x) {
-        const u32 next = item + gridDim.x;
         const u32 blk = item & ((1u << a.s0) - 1);
         const u32 limb = limb_of(item);
         u64 *const g = a.data + (((size_t)limb << a.s0) + blk) * NS;  // uniform
@@ -257,8 +255,9 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
             // ---- pass 1: rows r = 0..7 (bits 12..10) of the column pair -------------------------------------------------
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                x[2 * r] = y[r].x;
-                x[2 * r + 1] = y[r].y;
+                const u64x2 v = *reinterpret_cast<const u64x2 *>(g + 1024 * r + voff);
+                x[2 * r] = v.x;
+                x[2 * r + 1] = v.y;
             }
 #pragma unroll
             for (int s = 0; s < 3; s++) {
@@ -268,15 +267,6 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
                     if (r & d) continue;
                     const Tw t = make_tw(NTT16_TWL(1u << s, (u32)r >> (3 - s)));
                     bfly2<false, true>(x[2 * r], x[2 * (r + d)], t, x[2 * r + 1], x[2 * (r + d) + 1], t, mc);
-                }
-                if (s == 0) {
-                    // The next slice: issued here, one stage after the previous slice's stores (the vector-memory queue is in
-                    // order; loads right behind 64 KiB of stores stall at issue), and ahead of every per-lane twiddle load of
-                    // this slice (passes 1 and 2 take their twiddles through the scalar cache), so that no vmcnt wait for a
-                    // twiddle ends up waiting for HBM.
-                    NTT16_FENCE();
-                    if (next < a.nitems) NTT16_LOAD_SLICE(next);
-                    NTT16_FENCE();
                 }
             }
             NTT16_STAMP(1);
@@ -398,9 +388,12 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
             NTT16_LOAD4(t12, 4, 8);
             if (a.flags & F_STD_IN) {
                 // standard order: coalesced rows through LDS
+                u64x2 yv[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) yv[r] = *reinterpret_cast<const u64x2 *>(g + 1024 * r + voff);
                 __syncthreads();  // previous slice's readers of the image are done
 #pragma unroll
-                for (int r = 0; r < 8; r++) *reinterpret_cast<u64x2 *>(p1 + 1088 * r) = y[r];
+                for (int r = 0; r < 8; r++) *reinterpret_cast<u64x2 *>(p1 + 1088 * r) = yv[r];
                 __syncthreads();
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -423,8 +416,9 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    x[2 * j] = y[j].x;
-                    x[2 * j + 1] = y[j].y;
+                    const u64x2 v = *reinterpret_cast<const u64x2 *>(g + 2 * T * j + voff);
+                    x[2 * j] = v.x;
+                    x[2 * j + 1] = v.y;
                 }
             }
             NTT16_FENCE();
@@ -483,11 +477,6 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
             for (int k = 0; k < 16; k++) p3[4 * k + 2 * (k >> 3)] = x[k];
             wave_sync();
             // ---- pass 2': stages 6..3 ------------------------------------------------------------------------------------------
-            // the next slice, issued behind the last per-lane twiddle load of this one; it has passes 2' and 1' (scalar-cache
-            // twiddles) to arrive
-            NTT16_FENCE();
-            if (next < a.nitems) NTT16_LOAD_SLICE(next);
-            NTT16_FENCE();
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = p2[68 * k];
 #pragma unroll
@@ -545,7 +534,6 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
 }
 #undef NTT16_LOAD3
 #undef NTT16_LOAD3H
-#undef NTT16_LOAD_SLICE
 #undef NTT16_LOAD4
 #undef NTT16_FENCE
 #undef NTT16_TWL

@@ -87,7 +87,9 @@ struct piehip_ctx {
     bool fold_on = false;     // outermost NTT stage folded into the coefficient-wise kernels (N >= 2^14)
     u32 *d_inv_pos = nullptr; // EVALUATION position -> slot
     u32 *d_sigma_inv = nullptr;  // lane-order position -> standard position (identity for small rings)
-    u32 sigma_T = 0;             // threads per slice of the transform that defines the lane order (slice size / 32)
+    u32 sigma_T = 0;             // threads per slice of the transform that defines the lane order
+    u32 sigma_kp = 16;           // ... and coefficient pairs per thread (16: kernels_ntt_fast.hip, 8: ntt16_kernel.h)
+    u64 *d_twk16 = nullptr;      // ntt16_kernel.h tables (2^13-coefficient slices: ring 2^13, or ring 2^14 folded)
     bool small_moduli = false;   // all Q and P moduli in (2^59, 2^60): v_mad_u64_u32 column accumulators, one-word Barrett
     bool sigma_on = false;       // the register-blocked NTT (and hence the lane order) applies to this context
     u64 *d_evk_sigma = nullptr, *d_masks_sigma = nullptr;  // lane-ordered copies of key and masks
@@ -270,7 +272,9 @@ static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, c
     const double W = 8.0 * N;
     set_small_moduli(h->small_moduli);
     bool fused = false;
-    if (h->sigma_on && h->d_twc && h->hp.logN <= 14) {  // digit lift inside the transform's load phase
+    // digit lift inside the transform's load phase (the 32-coefficient kernel; contexts whose lane order is the 16-coefficient
+    // kernel's take the digits kernel + transform below)
+    if (h->sigma_on && h->d_twc && h->hp.logN <= 14 && !(sigma && ntt16_applies(h->plan, fold && h->fold_on))) {
         ProfScope ps(h, PIEHIP_K_NTT_FWD, 16.0 * N * nb * L * L);
         fused = launch_ntt_digits(h->plan, w.d2c, w.dig, nb, L, sigma && h->sigma_on, fold && h->fold_on, h->stream);
     }
@@ -287,7 +291,7 @@ static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, c
         ProfScope ps(h, PIEHIP_K_RELIN, W * (nb * ((double)L * L + 2 * L + 2 * L + (mask ? L : 0)) + 2.0 * L * L));
         launch_relin_mac(h->d_dc, N, L, w.d01, 2 * LN, w.dig, key, mask, out, nb, h->stream,
                          (sigma && h->sigma_on) ? h->d_sigma_inv : nullptr, key_stride, key_group,
-                         (sigma && h->sigma_on) ? h->sigma_T : 0);
+                         (sigma && h->sigma_on) ? h->sigma_T : 0, h->sigma_kp);
     }
 }
 
@@ -454,6 +458,17 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
                 CHK_(hipMemcpy(h->d_twc_fold, all.data(), all.size() * sizeof(u64), hipMemcpyHostToDevice));
                 h->fold_on = true;
             }
+            if (h->hp.logN == 13 || h->hp.logN == 14) {  // 2^13-coefficient slices: the 16-coefficients-per-thread kernel
+                const u32 s16 = h->hp.logN - 13;
+                all.clear();
+                for (u32 a = 0; a <= M; a++)
+                    for (u32 dir = 0; dir < 2; dir++) {
+                        build_twk16_table(&pairs[((size_t)a * 2 + dir) * 2 * N], s16, one);
+                        all.insert(all.end(), one.begin(), one.end());
+                    }
+                CHK_(hipMalloc((void **)&h->d_twk16, all.size() * sizeof(u64)));
+                CHK_(hipMemcpy(h->d_twk16, all.data(), all.size() * sizeof(u64), hipMemcpyHostToDevice));
+            }
         }
     }
     {
@@ -464,9 +479,18 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
     }
 #undef CHK_
     h->plan.tables = h->d_tables;
+    h->plan.twp = h->d_twp;
+    h->plan.logN = h->hp.logN;
+    h->plan.force_generic = false;
+    if (h->hp.logN == 13) h->plan.twk16 = h->d_twk16;
+    if (h->hp.logN == 14) h->plan.twk16_fold = h->d_twk16;
+    const bool use16 = ntt16_applies(h->plan, h->fold_on);  // which kernel defines this context's lane order
     {
         std::vector<u32> smap;
-        ntt_sigma_inverse_map(h->hp.logN, h->d_twc ? (h->fold_on ? 1u : ntt_fast_s0(h->hp.logN)) : ~0u, smap);
+        if (use16)
+            ntt16_sigma_inverse_map(h->hp.logN, h->fold_on ? 1u : 0u, smap);
+        else
+            ntt_sigma_inverse_map(h->hp.logN, h->d_twc ? (h->fold_on ? 1u : ntt_fast_s0(h->hp.logN)) : ~0u, smap);
         if (hipMalloc((void **)&h->d_sigma_inv, sizeof(u32) * N) != hipSuccess ||
             hipMemcpy(h->d_sigma_inv, smap.data(), sizeof(u32) * N, hipMemcpyHostToDevice) != hipSuccess) {
             piehip_destroy(h);
@@ -475,7 +499,8 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
         h->sigma_on = h->d_twc != nullptr;
         if (h->sigma_on) {
             const u32 s0 = h->fold_on ? 1u : ntt_fast_s0(h->hp.logN);
-            h->sigma_T = (N >> s0) / 32;
+            h->sigma_T = use16 ? (N >> s0) / 16 : (N >> s0) / 32;
+            h->sigma_kp = use16 ? 8 : 16;
         }
         h->small_moduli = true;
         for (u32 a = 0; a < M; a++)
@@ -517,6 +542,7 @@ int piehip_destroy(piehip_handle h)
     if (h->d_twp) (void)hipFree(h->d_twp);
     if (h->d_twc) (void)hipFree(h->d_twc);
     if (h->d_twc_fold) (void)hipFree(h->d_twc_fold);
+    if (h->d_twk16) (void)hipFree(h->d_twk16);
     if (h->d_inv_pos) (void)hipFree(h->d_inv_pos);
     if (h->d_sigma_inv) (void)hipFree(h->d_sigma_inv);
     dev_free(&h->d_evk_sigma);
