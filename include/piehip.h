@@ -129,6 +129,16 @@ int piehip_run(piehip_handle h);
 /* the same, with the result ciphertexts written straight into caller-owned HBM d_results[b][2][L][N] (e.g. the RCCL
  * gather buffer) instead of the handle's result buffer */
 int piehip_run_into(piehip_handle h, void *d_results);
+/* The online phase in one call, as the reference server times it (BatchedFHEPSIServer.cpp:98-108): setMinusCompareElement +
+ * setIndex + run + getResultList with the query in HOST memory.  The index matrix is uploaded one inner hash function (row of
+ * E ciphertexts) at a time on a copy queue, stage A of row h starts as soon as that row has landed, and each queue group's
+ * slice of the result list is downloaded as soon as the group is done.  Synchronous: results (may be NULL) are complete on
+ * return.  Fastest with piehip_host_buffers' pinned arrays (a deserialiser writes the towers straight into them); any host
+ * pointers work. */
+int piehip_run_host(piehip_handle h, const uint64_t *idx /*[K][E][2][L][N]*/, const uint64_t *minus /*[2][L][N]*/,
+                    uint64_t *results /*[b][2][L][N]*/);
+/* page-locked staging arrays owned by the handle (valid until the database shape changes or the handle is destroyed) */
+int piehip_host_buffers(piehip_handle h, uint64_t **idx, uint64_t **minus, uint64_t **results);
 /* Stream order.  run() works on the handle's own queues (piehip_set_run_streams); it waits for the handle's stream
  * where it must (new inputs; the result buffer), and the handle's stream waits for the run in the next call of any
  * other entry point -- piehip_join() does only that, piehip_sync() also blocks the host.  Work queued on the handle's

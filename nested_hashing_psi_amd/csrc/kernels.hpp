@@ -88,9 +88,9 @@ void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_
 // Stage A: acc[b][K][2][L][N] = sum_j idx[h][j] (.) db[h][beta][j] + minus    (BatchedFHEHIPPIE.cpp:101-116)
 // small_moduli: every RNS modulus is < 2^60 (enables the v_mad_u64_u32 column-accumulator kernel)
 // bstride: bin-layer count of the database array db[K][bstride][E][L][N] when only b <= bstride layers (starting at the
-// layer db points to) are evaluated; 0 = b
+// layer db points to) are evaluated; 0 = b.  h0, hn: only the inner hash functions [h0, h0 + hn) (hn = 0: all from h0)
 void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
-                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride = 0);
+                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride = 0, u32 h0 = 0, u32 hn = 0);
 
 // (per-host-thread switch, set from the context before its launches: all Q and P moduli lie in (2^59, 2^60), which lets
 // the base-conversion and key-switch kernels use the carry-free v_mad_u64_u32 column accumulators and one-word Barrett)

@@ -33,12 +33,12 @@ typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 template <int BPT>
 __global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
                                                       const u64 *__restrict__ idx, const u64 *__restrict__ minus,
-                                                      const u64 *__restrict__ db, u64 *__restrict__ acc, u32 bstride)
+                                                      const u64 *__restrict__ db, u64 *__restrict__ acc, u32 bstride, u32 h0)
 {
     const u32 n = 2 * (blockIdx.x * TPB + threadIdx.x);
     const u32 l = blockIdx.y;
     const u32 groups = b / BPT;
-    const u32 h = blockIdx.z / groups, beta0 = (blockIdx.z % groups) * BPT;
+    const u32 h = h0 + blockIdx.z / groups, beta0 = (blockIdx.z % groups) * BPT;
     if (n >= N) return;
     const Mod m = dc->mod[l];
     const size_t LN = (size_t)L * N;
@@ -96,13 +96,13 @@ __global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *__restric
 template <int BPT, int CPT>
 __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
                                                           const u64 *__restrict__ idx, const u64 *__restrict__ minus,
-                                                          const u64 *__restrict__ db, u64 *__restrict__ acc, u32 bstride)
+                                                          const u64 *__restrict__ db, u64 *__restrict__ acc, u32 bstride, u32 h0)
 {
     // CPT coefficients per thread: 2 -> 16-byte lanes; 1 -> 8-byte lanes, half the accumulator registers
     const u32 n = CPT * (blockIdx.x * TPB + threadIdx.x);
     const u32 l = blockIdx.y;
     const u32 groups = b / BPT;
-    const u32 h = blockIdx.z / groups, beta0 = (blockIdx.z % groups) * BPT;
+    const u32 h = h0 + blockIdx.z / groups, beta0 = (blockIdx.z % groups) * BPT;
     if (n >= N) return;
     const Mod m = dc->mod[l];
     const size_t LN = (size_t)L * N;
@@ -183,9 +183,10 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
 }
 
 void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
-                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride)
+                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride, u32 h0, u32 hn)
 {
     if (!bstride) bstride = b;
+    if (!hn) hn = K - h0;
     // bin layers per thread: the largest divisor of b that keeps the accumulators in registers
     const bool mad = small_moduli && E <= COLACC_MAX_TOTAL;
     const int cap = mad ? 7 : 8;
@@ -198,15 +199,15 @@ void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, cons
     // the mad kernel keeps 6 accumulator registers per (layer, component, coefficient): above 4 layers per
     // thread it handles one coefficient per thread (8-byte lanes) to stay at >= 2 waves per SIMD
     const int cpt = (mad && bpt > 4) ? 1 : 2;
-    dim3 grid((N / cpt + TPB - 1) / TPB, L, K * (b / bpt));
+    dim3 grid((N / cpt + TPB - 1) / TPB, L, hn * (b / bpt));
 #define SA(B_)                                                                                                       \
     do {                                                                                                             \
-        if (mad && cpt == 1) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 1>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride); \
-        else if (mad) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 2>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride); \
-        else hipLaunchKernelGGL(stage_a_kernel<B_>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride);  \
+        if (mad && cpt == 1) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 1>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0); \
+        else if (mad) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 2>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0); \
+        else hipLaunchKernelGGL(stage_a_kernel<B_>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0);  \
     } while (0)
     switch (bpt) {
-        case 8: hipLaunchKernelGGL(stage_a_kernel<8>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride); break;
+        case 8: hipLaunchKernelGGL(stage_a_kernel<8>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0); break;
         case 7: SA(7); break;
         case 6: SA(6); break;
         case 5: SA(5); break;

@@ -79,6 +79,13 @@ struct piehip_ctx {
     bool inputs_dirty = true;                     // inputs / keys / database changed on the handle's stream since the last run()
     hipEvent_t wait_before_results = nullptr;     // set while run() enqueues a group: its result-writing kernel waits for this
     bool pending_join = false;                    // run() left work on the bin-layer queues that the handle's stream has not waited for
+    // piehip_run_host: copy queue, one "row landed" event per inner hash function, pinned staging owned by the handle
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> ev_h2d;               // [K]: index-matrix row h (and, for h = 0, the minus element) is in HBM
+    hipEvent_t ev_copy_gate = nullptr;
+    const hipEvent_t *row_events = nullptr;       // set while piehip_run_host enqueues: stage A of row h waits for row_events[h]
+    u64 *pin_idx = nullptr, *pin_minus = nullptr, *pin_res = nullptr;
+    size_t pin_idx_words = 0, pin_res_words = 0;
     DevConsts *d_dc = nullptr;
     u64 *d_tables = nullptr;  // [(M+1)][4][N]
     u64 *d_twp = nullptr;     // [(M+1)][2][N][2] interleaved {w, w_shoup}
@@ -562,6 +569,15 @@ int piehip_destroy(piehip_handle h)
         (void)hipStreamSynchronize(s);
         (void)hipStreamDestroy(s);
     }
+    if (h->copy_stream) {
+        (void)hipStreamSynchronize(h->copy_stream);
+        (void)hipStreamDestroy(h->copy_stream);
+    }
+    for (hipEvent_t e : h->ev_h2d) (void)hipEventDestroy(e);
+    if (h->ev_copy_gate) (void)hipEventDestroy(h->ev_copy_gate);
+    if (h->pin_idx) (void)hipHostFree(h->pin_idx);
+    if (h->pin_minus) (void)hipHostFree(h->pin_minus);
+    if (h->pin_res) (void)hipHostFree(h->pin_res);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (hipEvent_t e : h->ev_join) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -967,6 +983,17 @@ int piehip_set_minus_device(piehip_handle h, const void *d_minus)
     return PIEHIP_OK;
 }
 
+// bin layers of queue group g of ng.  Two groups take 4/7 and 3/7 of the layers: measured 3.5 % faster than equal halves at
+// b = 14 (8 + 6: the ragged transform launches of the two queues fit the workgroup slots better than 7 + 7).
+static u32 run_group_size(u32 b, u32 ng, u32 g)
+{
+    if (ng == 2) {
+        const u32 first = (4 * b + 3) / 7;
+        return g == 0 ? first : b - first;
+    }
+    return b / ng + (g < b % ng ? 1 : 0);
+}
+
 // Bin layers [b0, b0 + nb) of run() on the handle's current stream: stage A, then the product chain.
 static void enqueue_run_bins(piehip_ctx *h, u32 b0, u32 nb, u64 *results)
 {
@@ -986,7 +1013,15 @@ static void enqueue_run_bins(piehip_ctx *h, u32 b0, u32 nb, u64 *results)
     const u64 *masks = (h->sigma_on ? h->d_masks_sigma : h->d_masks) + (size_t)b0 * LN;
     {   // stage A: all inner products of these bin layers in one launch (BatchedFHEHIPPIE.cpp:101-116)
         ProfScope ps(h, PIEHIP_K_STAGE_A, W * ((double)nb * K * E * L + (double)K * E * 2 * L + 2.0 * L + (double)nb * K * 2 * L));
-        launch_stage_a(h->d_dc, N, L, K, nb, E, h->d_idx, h->d_minus, h->d_db + (size_t)b0 * E * LN, acc, h->stream, h->small_moduli, b);
+        if (h->row_events) {
+            // the index matrix is still arriving over PCIe: one launch per inner hash function, each behind its own row
+            for (u32 hf = 0; hf < K; hf++) {
+                (void)hipStreamWaitEvent(h->stream, h->row_events[hf], 0);
+                launch_stage_a(h->d_dc, N, L, K, nb, E, h->d_idx, h->d_minus, h->d_db + (size_t)b0 * E * LN, acc, h->stream, h->small_moduli, b, hf, 1);
+            }
+        } else {
+            launch_stage_a(h->d_dc, N, L, K, nb, E, h->d_idx, h->d_minus, h->d_db + (size_t)b0 * E * LN, acc, h->stream, h->small_moduli, b);
+        }
     }
     // every accumulator enters a ct x ct product exactly once: switch them all to COEFFICIENT format
     const bool xq = xq_reuse(h) && K > 1;
@@ -1048,14 +1083,7 @@ int piehip_run_into(piehip_handle h, void *d_results)
         HIPCHK(hipEventRecord(h->ev_fork, restore.s));
         u32 b0 = 0;
         for (u32 g = 0; g < ng; g++) {
-            u32 nb = b / ng + (g < b % ng ? 1 : 0);
-            if (ng == 2) {
-                // two groups of 4/7 and 3/7 of the layers: measured 3.5 % faster than equal halves at b = 14 (8 + 6: the
-                // ragged transform launches of the two queues fit the 512 workgroup slots better than 7 + 7); a queue
-                // offset of half a chain made no difference
-                const u32 first = (4 * b + 3) / 7;
-                nb = g == 0 ? first : b - first;
-            }
+            const u32 nb = run_group_size(b, ng, g);
             if (h->inputs_dirty) HIPCHK(hipStreamWaitEvent(h->side_streams[g], h->ev_fork, 0));
             h->stream = h->side_streams[g];
             h->wait_before_results = h->inputs_dirty ? nullptr : h->ev_fork;
@@ -1079,6 +1107,96 @@ int piehip_run(piehip_handle h)
     if (!h) return fail(PIEHIP_EINVAL, "null handle");
     if (!h->d_out) return fail(PIEHIP_ESTATE, "run: database not loaded");
     return piehip_run_into(h, h->d_out);
+}
+
+static int host_path_setup(piehip_ctx *h)
+{
+    if (!h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (!h->ev_copy_gate) HIPCHK(hipEventCreateWithFlags(&h->ev_copy_gate, hipEventDisableTiming));
+    while (h->ev_h2d.size() < h->K) {
+        hipEvent_t e = nullptr;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->ev_h2d.push_back(e);
+    }
+    return PIEHIP_OK;
+}
+
+int piehip_host_buffers(piehip_handle h, uint64_t **idx, uint64_t **minus, uint64_t **results)
+{
+    NEED_RO(h);
+    if (!h->K) return fail(PIEHIP_ESTATE, "load the database first (the buffer sizes depend on K, E and b)");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t iw = (size_t)h->K * h->E * 2 * h->LN(), rw = (size_t)h->b * 2 * h->LN();
+    if (h->pin_idx && h->pin_idx_words != iw) {
+        (void)hipHostFree(h->pin_idx);
+        h->pin_idx = nullptr;
+    }
+    if (h->pin_res && h->pin_res_words != rw) {
+        (void)hipHostFree(h->pin_res);
+        h->pin_res = nullptr;
+    }
+    if (!h->pin_idx) HIPCHK(hipHostMalloc((void **)&h->pin_idx, iw * sizeof(u64), hipHostMallocDefault));
+    if (!h->pin_minus) HIPCHK(hipHostMalloc((void **)&h->pin_minus, 2 * h->LN() * sizeof(u64), hipHostMallocDefault));
+    if (!h->pin_res) HIPCHK(hipHostMalloc((void **)&h->pin_res, rw * sizeof(u64), hipHostMallocDefault));
+    h->pin_idx_words = iw;
+    h->pin_res_words = rw;
+    if (idx) *idx = h->pin_idx;
+    if (minus) *minus = h->pin_minus;
+    if (results) *results = h->pin_res;
+    return PIEHIP_OK;
+}
+
+int piehip_run_host(piehip_handle h, const uint64_t *idx, const uint64_t *minus, uint64_t *results)
+{
+    if (!h) return fail(PIEHIP_EINVAL, "null handle");
+    if (!idx || !minus) return fail(PIEHIP_EINVAL, "null input");
+    if (!h->K || !h->d_db) return fail(PIEHIP_ESTATE, "run: database not loaded");
+    if (!h->d_evk) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = host_path_setup(h);
+    if (rc) return rc;
+    const size_t LN = h->LN(), row = (size_t)h->E * 2 * LN;
+    if (!h->d_idx_own && (rc = dev_alloc(&h->d_idx_own, (size_t)h->K * row))) return rc;
+    if (!h->d_minus_own && (rc = dev_alloc(&h->d_minus_own, 2 * LN))) return rc;
+    // the uploads may not overtake a run that still reads the input buffers: gate the copy queue behind everything queued so far
+    join_pending(h);
+    HIPCHK(hipEventRecord(h->ev_copy_gate, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_copy_gate, 0));
+    HIPCHK(hipMemcpyAsync(h->d_minus_own, minus, 2 * LN * sizeof(u64), hipMemcpyHostToDevice, h->copy_stream));
+    for (u32 hf = 0; hf < h->K; hf++) {
+        HIPCHK(hipMemcpyAsync(h->d_idx_own + (size_t)hf * row, idx + (size_t)hf * row, row * sizeof(u64), hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK(hipEventRecord(h->ev_h2d[hf], h->copy_stream));
+    }
+    h->d_idx = h->d_idx_own;
+    h->d_minus = h->d_minus_own;
+    mark_dirty(h);
+    h->row_events = h->ev_h2d.data();
+    rc = piehip_run_into(h, h->d_out);
+    h->row_events = nullptr;
+    if (rc) return rc;
+    if (results) {
+        // every queue group's slice of the result list leaves as soon as that group is done
+        if (h->pending_join) {
+            const size_t nq = h->side_streams.size();
+            const u32 ng = (u32)std::min<size_t>(h->run_streams ? h->run_streams : nq, std::min<size_t>(nq, h->b));
+            u32 b0 = 0;
+            for (u32 g = 0; g < ng; g++) {
+                const u32 nb = run_group_size(h->b, ng, g);
+                HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_join[g], 0));
+                HIPCHK(hipMemcpyAsync(results + (size_t)b0 * 2 * LN, h->d_out + (size_t)b0 * 2 * LN, (size_t)nb * 2 * LN * sizeof(u64),
+                                      hipMemcpyDeviceToHost, h->copy_stream));
+                b0 += nb;
+            }
+        } else {
+            HIPCHK(hipEventRecord(h->ev_copy_gate, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_copy_gate, 0));
+            HIPCHK(hipMemcpyAsync(results, h->d_out, (size_t)h->b * 2 * LN * sizeof(u64), hipMemcpyDeviceToHost, h->copy_stream));
+        }
+        HIPCHK(hipStreamSynchronize(h->copy_stream));
+    }
+    join_pending(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PIEHIP_OK;
 }
 
 int piehip_join(piehip_handle h)

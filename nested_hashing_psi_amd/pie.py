@@ -298,6 +298,29 @@ class BatchedFHEHIPPIE:
         if sync:
             _check(lib().piehip_sync(self.cc._h))
 
+    def hostBuffers(self):
+        """page-locked numpy views (index matrix [K][E][2][L][N], minus element [2][L][N], result list [b][2][L][N]) owned by the
+        library: a deserialiser that writes the towers straight into them saves the staging copy of the upload"""
+        pi, pm, pr = u64p(), u64p(), u64p()
+        _check(lib().piehip_host_buffers(self.cc._h, C.byref(pi), C.byref(pm), C.byref(pr)))
+        L, N = self.cc.L, self.cc.N
+        mk = lambda ptr, shape: np.ctypeslib.as_array(ptr, shape=shape)
+        return mk(pi, (self.K, self.E, 2, L, N)), mk(pm, (2, L, N)), mk(pr, (self.b, 2, L, N))
+
+    def runHost(self, indexMatrix, minusCompareElement, results=None):
+        """setMinusCompareElement + setIndex + run + getResultList in one pipelined call (piehip_run_host): the query is in host
+        memory, row h of the index matrix uploads while stage A of row h - 1 runs, results download per queue group"""
+        a, ap = _u64(indexMatrix)
+        m, mp = _u64(minusCompareElement)
+        if a.shape != (self.K, self.E, 2, self.cc.L, self.cc.N) or m.shape != (2, self.cc.L, self.cc.N):
+            raise ValueError("index matrix must be [K][E] ciphertexts, the minus element one ciphertext")
+        if results is None:
+            if getattr(self, "_results", None) is None:
+                self._results = np.zeros((self.b, 2, self.cc.L, self.cc.N), dtype=np.uint64)
+            results = self._results
+        _check(lib().piehip_run_host(self.cc._h, ap, mp, results.ctypes.data_as(u64p)))
+        return results
+
     def join(self):
         """order the context's stream behind the runs queued so far (no host wait)"""
         _check(lib().piehip_join(self.cc._h))

@@ -501,6 +501,38 @@ def test_run_pipelining_and_result_buffers(ob, pie, streams):
 
 
 # ---- caller-supplied moduli: the paths that the default 60-bit chain never takes ---------------------------------
+@pytest.mark.parametrize("N,L,K,E,b", [(4096, 2, 2, 5, 5), (16384, 4, 2, 3, 4), (8192, 3, 3, 4, 3)])
+def test_run_host_pipelined_call_matches_separate_calls(ob, pie, N, L, K, E, b):
+    """piehip_run_host (row-wise upload under stage A, per-group download) == setMinusCompareElement + setIndex + run +
+    getResultList == the oracle; from pageable arrays and from the library's page-locked staging arrays; consecutive
+    queries differ, and a plain run() afterwards still sees the right inputs"""
+    t = T16 if N == 4096 else T32
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(N + b)
+    db, masks, evk = rand_limbs(rng, cc.q, (K, b, E), N), rand_limbs(rng, cc.q, (b,), N), rand_limbs(rng, cc.q, (L, 2), N)
+    cc.load_relin_key(evk)
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    pi, pm, pr = op.hostBuffers()
+    for q in range(3):
+        idx, minus = rand_limbs(rng, cc.q, (K, E, 2), N), rand_limbs(rng, cc.q, (2,), N)
+        want = o.pie_run(idx, minus, db, masks, evk)
+        if q == 1:   # the staging arrays
+            pi[...] = idx
+            pm[...] = minus
+            got = op.runHost(pi, pm, pr)
+        else:
+            got = op.runHost(idx, minus)
+        assert (got == want).all()
+    op.run()   # inputs of the last run_host are still set
+    assert (op.getResultList() == want).all()
+    for streams in (1, 0):
+        cc.set_run_streams(streams)
+        idx, minus = rand_limbs(rng, cc.q, (K, E, 2), N), rand_limbs(rng, cc.q, (2,), N)
+        assert (op.runHost(idx, minus) == o.pie_run(idx, minus, db, masks, evk)).all()
+    cc.close()
+
+
 @pytest.mark.parametrize("N,L,t,below,what", [
     (4096, 3, T32, (1 << 61) - 1, "61-bit primes: no lazy-residue NTT, no mad arithmetic"),
     (4096, 2, T16, 1 << 50, "50-bit primes: register-blocked NTT, 128-bit Barrett instead of the one-word form"),

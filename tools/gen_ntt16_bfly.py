@@ -13,7 +13,7 @@ Register use of stream i: n = 11 (forward) or 13 (inverse) fixed VGPRs v[128 - n
 """
 import os
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nested_hashing_psi_amd", "csrc", "ntt16_bfly.inc")
+OUT = os.environ.get("NTT16_BFLY_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nested_hashing_psi_amd", "csrc", "ntt16_bfly.inc")
 
 
 NREG = {False: 11, True: 13}  # fixed VGPRs per stream: forward (CT), inverse (GS)
@@ -27,7 +27,7 @@ class Regs:
     def __init__(self, i, gs):
         n = NREG[gs]
         self.n = n
-        self.base = 128 - n * (i + 1)
+        self.base = 128 - n * (i + 1) - int(os.environ.get('NTT16_BASE_SHIFT', '0'))
         b = self.base
         self.X = b           # 2 bh
         self.M = b           # sign mask
