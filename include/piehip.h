@@ -149,6 +149,11 @@ int piehip_sync(piehip_handle h);
  * one group's launches are filled by another group's; n = 1 serialises everything on the handle's stream (per-kernel
  * timing), 0 = the default (2).  The results are complete on the handle's stream either way. */
 int piehip_set_run_streams(piehip_handle h, uint32_t n);
+/* on != 0: run() / run_into() replay one captured hipGraph (all launches of both queue groups, forked from and joined back to
+ * the handle's stream) instead of enqueueing ~26 launches; re-captured when the input arrays, the result buffer or the queue
+ * count change.  Amortises the launch path when a handle evaluates few bin layers (one rank's share of a sharded server);
+ * consecutive runs then do not overlap each other.  Off by default. */
+int piehip_set_graph(piehip_handle h, int on);
 /* getResultList (BatchedFHEHIPPIE.hpp:35-38): out[b][2][L][N] */
 int piehip_get_results(piehip_handle h, uint64_t *out);
 /* device address of the result buffer [b][2][L][N] (valid until destroy); for the RCCL gather */

@@ -79,6 +79,11 @@ struct piehip_ctx {
     bool inputs_dirty = true;                     // inputs / keys / database changed on the handle's stream since the last run()
     hipEvent_t wait_before_results = nullptr;     // set while run() enqueues a group: its result-writing kernel waits for this
     bool pending_join = false;                    // run() left work on the bin-layer queues that the handle's stream has not waited for
+    // piehip_set_graph: run() as one captured hipGraph per (inputs, result buffer, queue count), replayed on the handle's stream
+    bool use_graph = false;
+    hipGraphExec_t gexec = nullptr;
+    const void *g_idx = nullptr, *g_minus = nullptr, *g_res = nullptr;
+    u32 g_ng = 0;
     // piehip_run_host: copy queue, one "row landed" event per inner hash function, pinned staging owned by the handle
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> ev_h2d;               // [K]: index-matrix row h (and, for h = 0, the minus element) is in HBM
@@ -147,6 +152,12 @@ static void join_pending(piehip_ctx *h)
 }
 
 static void mark_dirty(piehip_ctx *h) { h->inputs_dirty = true; }
+
+static void drop_graph(piehip_ctx *h)
+{
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    h->gexec = nullptr;
+}
 
 static const char *KNAMES[PIEHIP_NKERNELS] = {"stage_a_mac", "ntt_fwd", "ntt_inv",  "expand",   "tensor",    "scale_round",
                                               "digits",      "relin",   "mask_mul", "encode",   "automorph", "other"};
@@ -569,6 +580,7 @@ int piehip_destroy(piehip_handle h)
         (void)hipStreamSynchronize(s);
         (void)hipStreamDestroy(s);
     }
+    drop_graph(h);
     if (h->copy_stream) {
         (void)hipStreamSynchronize(h->copy_stream);
         (void)hipStreamDestroy(h->copy_stream);
@@ -653,6 +665,7 @@ static int make_masks_sigma(piehip_ctx *h)
 
 static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E)
 {
+    drop_graph(h);  // the captured launches hold the addresses and shapes of the buffers below
     if (K < 2) return fail(PIEHIP_EINVAL, "Cuckoo Table needs more than one hash function!");  // CuckooHashTable.cpp:39-42
     if (b < 1 || E < 1) return fail(PIEHIP_EINVAL, "Bin size needs to be at least of size one!");
     const size_t LN = h->LN();
@@ -1070,6 +1083,55 @@ int piehip_run_into(piehip_handle h, void *d_results)
     //     so back-to-back runs of one query batch keep every queue busy across run boundaries.
     const size_t nq = h->side_streams.size();
     const u32 ng = (u32)std::min<size_t>(h->run_streams ? h->run_streams : nq, std::min<size_t>(nq, b));
+    if (h->use_graph && !h->profiling && !h->row_events) {
+        // One graph launch instead of ~13 kernel launches and 2 event operations per queue group: the same two chains, forked
+        // from and joined back to the handle's stream inside the graph (so consecutive runs do not overlap each other, which
+        // the eager path's lazy join allows).
+        if (!h->gexec || h->g_idx != h->d_idx || h->g_minus != h->d_minus || h->g_res != d_results || h->g_ng != ng) {
+            drop_graph(h);
+            join_pending(h);
+            struct Restore {
+                piehip_ctx *h;
+                hipStream_t s;
+                ~Restore() { h->stream = s; }
+            } restore{h, h->stream};
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(restore.s, hipStreamCaptureModeThreadLocal));
+            hipError_t ce = hipSuccess;
+            if (ng > 1) {
+                ce = hipEventRecord(h->ev_fork, restore.s);
+                u32 b0 = 0;
+                for (u32 g = 0; g < ng && ce == hipSuccess; g++) {
+                    const u32 nb = run_group_size(b, ng, g);
+                    ce = hipStreamWaitEvent(h->side_streams[g], h->ev_fork, 0);
+                    h->stream = h->side_streams[g];
+                    enqueue_run_bins(h, b0, nb, (u64 *)d_results);
+                    if (ce == hipSuccess) ce = hipEventRecord(h->ev_join[g], h->side_streams[g]);
+                    if (ce == hipSuccess) ce = hipStreamWaitEvent(restore.s, h->ev_join[g], 0);
+                    b0 += nb;
+                }
+                h->stream = restore.s;
+            } else {
+                enqueue_run_bins(h, 0, b, (u64 *)d_results);
+            }
+            const hipError_t ee = hipStreamEndCapture(restore.s, &graph);
+            if (ce != hipSuccess || ee != hipSuccess || !graph) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return fail(PIEHIP_EHIP, std::string("run: graph capture failed: ") + hipGetErrorString(ce != hipSuccess ? ce : ee));
+            }
+            const hipError_t ie = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) {
+                h->gexec = nullptr;
+                return fail(PIEHIP_EHIP, std::string("run: hipGraphInstantiate: ") + hipGetErrorString(ie));
+            }
+            h->g_idx = h->d_idx, h->g_minus = h->d_minus, h->g_res = d_results, h->g_ng = ng;
+        }
+        join_pending(h);
+        HIPCHK(hipGraphLaunch(h->gexec, h->stream));
+        mark_dirty(h);  // the workspace is in use on the handle's stream
+        return PIEHIP_OK;
+    }
     if (ng > 1) {
         struct Restore {
             piehip_ctx *h;
@@ -1202,6 +1264,14 @@ int piehip_run_host(piehip_handle h, const uint64_t *idx, const uint64_t *minus,
 int piehip_join(piehip_handle h)
 {
     NEED_RO(h);
+    return PIEHIP_OK;
+}
+
+int piehip_set_graph(piehip_handle h, int on)
+{
+    NEED_RO(h);
+    h->use_graph = on != 0;
+    if (!on) drop_graph(h);
     return PIEHIP_OK;
 }
 

@@ -185,6 +185,10 @@ class PieContext:
         """run() spreads the bin layers over up to n HIP streams (0 = default, 1 = serial on the handle's stream)"""
         _check(lib().piehip_set_run_streams(self._h, int(n)))
 
+    def set_graph(self, on):
+        """run() as one captured hipGraph (piehip_set_graph)"""
+        _check(lib().piehip_set_graph(self._h, int(on)))
+
     def set_profiling(self, on):
         _check(lib().piehip_set_profiling(self._h, int(on)))
 

@@ -501,6 +501,41 @@ def test_run_pipelining_and_result_buffers(ob, pie, streams):
 
 
 # ---- caller-supplied moduli: the paths that the default 60-bit chain never takes ---------------------------------
+@pytest.mark.parametrize("streams", [0, 1])
+def test_run_as_captured_graph(ob, pie, streams):
+    """piehip_set_graph: the replayed graph computes what the eager launches compute; it is re-captured when the inputs, the
+    result buffer or the queue count change, and survives a database reload of another shape"""
+    N, L, t, K, E, b = 4096, 2, T16, 2, 4, 5
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(77 + streams)
+    evk = rand_limbs(rng, cc.q, (L, 2), N)
+    cc.load_relin_key(evk)
+    cc.set_run_streams(streams)
+    cc.set_graph(True)
+    for bb in (b, 3):
+        db, masks = rand_limbs(rng, cc.q, (K, bb, E), N), rand_limbs(rng, cc.q, (bb,), N)
+        op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+        for q in range(3):
+            idx, minus = rand_limbs(rng, cc.q, (K, E, 2), N), rand_limbs(rng, cc.q, (2,), N)
+            op.setMinusCompareElement(minus)
+            op.setIndex(idx)
+            want = o.pie_run(idx, minus, db, masks, evk)
+            op.run()
+            assert (op.getResultList() == want).all()
+            op.run(sync=False)          # replay, back to back
+            op.run()
+            assert (op.getResultList() == want).all()
+        cc.set_run_streams(1 - streams if streams else 1)   # another queue count: re-capture
+        op.run()
+        assert (op.getResultList() == want).all()
+        cc.set_run_streams(streams)
+    cc.set_graph(False)
+    op.run()
+    assert (op.getResultList() == want).all()
+    cc.close()
+
+
 @pytest.mark.parametrize("N,L,K,E,b", [(4096, 2, 2, 5, 5), (16384, 4, 2, 3, 4), (8192, 3, 3, 4, 3)])
 def test_run_host_pipelined_call_matches_separate_calls(ob, pie, N, L, K, E, b):
     """piehip_run_host (row-wise upload under stage A, per-group download) == setMinusCompareElement + setIndex + run +

@@ -48,7 +48,7 @@ def main():
         traffic[k] = dict(launches_in_run=n, fetch_bytes_per_launch=sum(f) / max(len(f), 1),
                           write_bytes_per_launch=sum(w) / max(len(w), 1),
                           hbm_bytes_per_launch=(sum(f) / max(len(f), 1)) + (sum(w) / max(len(w), 1)))
-    ntt = [k for k in traffic if k.startswith("ntt_")]
+    ntt = [k for k in traffic if k.startswith("ntt")]
     tot_b = sum(traffic[k]["hbm_bytes_per_launch"] * traffic[k]["launches_in_run"] for k in ntt)
     tot_n = sum(traffic[k]["launches_in_run"] for k in ntt)
     summary = dict(kernel_stats=stats, traffic=traffic,

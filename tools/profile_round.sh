@@ -12,7 +12,7 @@ OUT=$ROOT/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="$ROOT/bench.py --no-cpu-baseline --no-e2e"
+BENCH="$ROOT/bench.py --no-cpu-baseline --no-e2e --no-projection --no-ref-timer"
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/serial -o serial -- python3 $BENCH --streams 1 > $OUT/bench_serial.json 2> $OUT/serial.log
 echo "serial trace done"
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/default -o default -- python3 $BENCH > $OUT/bench_default.json 2> $OUT/default.log
