@@ -59,8 +59,17 @@ struct NttExtra {
 // a context uses one of the two for all lane-ordered arrays (ntt16_applies).  Returns false when it does not apply.
 void build_twk16_table(const u64 *nat_pairs, u32 s0, std::vector<u64> &out);
 void ntt16_sigma_inverse_map(u32 logN, u32 s0, std::vector<u32> &map);
+// dg (forward, lane order, mod_base 0, mod_count L): the BV key-switch digits of nb polynomials join the launch -- limb (bin, i, j)
+// of dig[nb][L][L][N] = transform of the centred lift into q_j of residue limb i of the COEFFICIENT polynomial d2 + bin * stride2
+// (replaces launch_digits + a second transform launch)
+struct Ntt16Digits {
+    const u64 *d2;
+    size_t stride2;
+    u64 *dig;
+    u32 nb, L;
+};
 bool launch_ntt16(const NttPlan &pl, bool folded, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, bool sigma,
-                  hipStream_t st, const NttExtra *ex);
+                  hipStream_t st, const NttExtra *ex, const Ntt16Digits *dg = nullptr);
 inline bool ntt16_applies(const NttPlan &pl, bool folded)
 {
     return !pl.force_generic && pl.twp && (folded ? (pl.twk16_fold && pl.logN == 14) : (pl.twk16 && pl.logN == 13));

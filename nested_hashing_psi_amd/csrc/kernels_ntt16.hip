@@ -16,7 +16,7 @@ void ntt16_sigma_inverse_map(u32 logN, u32 s0, std::vector<u32> &map)
 }
 
 bool launch_ntt16(const NttPlan &pl, bool folded, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, bool sigma,
-                  hipStream_t st, const NttExtra *ex)
+                  hipStream_t st, const NttExtra *ex, const Ntt16Digits *dg)
 {
     const u64 *twk = folded ? pl.twk16_fold : pl.twk16;
     const u32 s0 = folded ? 1u : 0u;
@@ -44,11 +44,27 @@ bool launch_ntt16(const NttPlan &pl, bool folded, u64 *data, u32 nlimbs, u32 mod
     a.copy_M = ex ? ex->copy_M : 1;
     a.stagger_from = ~0u;
     a.stagger_sleeps = 0;
+    a.lift_first = ~0u;
+    a.data2 = nullptr;
+    a.lift_src = nullptr;
+    a.lift_stride = 0;
+    a.lift_L = 1;
+    if (dg && !inverse) {  // the key-switch digits ride in the same launch: nb * L * L more limbs, lifted in the load phase
+        a.lift_first = a.nitems;
+        a.nitems += (dg->nb * dg->L * dg->L) << s0;
+        a.data2 = dg->dig;
+        a.lift_src = dg->d2;
+        a.lift_stride = dg->stride2;
+        a.lift_L = dg->L;
+    }
     constexpr size_t lds = (size_t)ntt16::LDS_WORDS * sizeof(u64);
-    static PerDeviceOnce attr[2];
-    if (attr[inverse ? 1 : 0].first_on_current_device()) {
+    const bool lift = a.lift_first != ~0u;
+    static PerDeviceOnce attr[3];
+    if (attr[inverse ? 1 : (lift ? 2 : 0)].first_on_current_device()) {
         if (inverse)
             (void)hipFuncSetAttribute((const void *)ntt16::ntt16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else if (lift)
+            (void)hipFuncSetAttribute((const void *)ntt16::ntt16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         else
             (void)hipFuncSetAttribute((const void *)ntt16::ntt16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
@@ -57,6 +73,8 @@ bool launch_ntt16(const NttPlan &pl, bool folded, u64 *data, u32 nlimbs, u32 mod
     const u32 grid = a.nitems < slots ? a.nitems : slots;
     if (inverse)
         hipLaunchKernelGGL(ntt16::ntt16_kernel<true>, dim3(grid), dim3(ntt16::T), lds, st, a);
+    else if (lift)
+        hipLaunchKernelGGL((ntt16::ntt16_kernel<false, true>), dim3(grid), dim3(ntt16::T), lds, st, a);
     else
         hipLaunchKernelGGL(ntt16::ntt16_kernel<false>, dim3(grid), dim3(ntt16::T), lds, st, a);
     return true;

@@ -130,6 +130,13 @@ struct Args {
     u32 copy_K, copy_L, copy_M;
     // workgroups from this index on begin stagger_sleeps x ~1000 cycles late (see the kernel); stagger_from >= grid: off
     u32 stagger_from, stagger_sleeps;
+    // forward: items [lift_first, nitems) are BV key-switch digits: limb (bin, i, j) of data2[nb][lift_L][lift_L][N]
+    // is the centred lift into q_j of residue limb i of the COEFFICIENT polynomial lift_src + bin * lift_stride, transformed;
+    // the lift (and, with two folded slices per limb, the outermost stage) happens in the load phase.  lift_first >= nitems: off
+    u64 *data2;
+    const u64 *lift_src;
+    size_t lift_stride;
+    u32 lift_first, lift_L;
 };
 enum : u32 {
     F_STD_IN = 1,    // inverse: EVALUATION input in standard (bit-reversed) order instead of lane order
@@ -182,13 +189,15 @@ inline u32 lane_to_std(u32 p)
 // LDS addresses are written as (one per-thread base) + (compile-time constant): phi is additive over multiples of 32, and a
 // base the compiler has to keep per row ends up in scratch memory.  Global addresses: uniform row base + one lane offset.
 #define NTT16_FENCE() __builtin_amdgcn_sched_barrier(0)
-#if defined(NTT16_PRIO) && NTT16_PRIO == 2
+// Wave priority falls as a wave advances through the passes of a slice.  The SIMD arbiter serves the highest priority, then the
+// oldest wave: with equal priorities the older of the two waves a workgroup has on each SIMD runs at full speed, the younger
+// on what is left, and the workgroup's barriers then wait for the younger half (measured: 9000 of 32000 cycles per slice).
+// With the priority tied to progress the wave that is behind is served first and all eight arrive together.
 #define NTT16_PASS_PRIO(p) __builtin_amdgcn_s_setprio(p)
-#else
-#define NTT16_PASS_PRIO(p)
-#endif
 
-template <bool INV>
+// LIFT (forward only): the launch may carry key-switch digit items (Args::lift_first); a separate instantiation, so that the
+// plain forward transform does not pay for the lift's registers
+template <bool INV, bool LIFT = false>
 __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
 {
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
@@ -223,14 +232,13 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
     if (blockIdx.x >= a.stagger_from) {
         for (u32 i = 0; i < a.stagger_sleeps; i++) __builtin_amdgcn_s_sleep(16);
     }
-#ifdef NTT16_PRIO
-    if (NTT16_PRIO == 1 && w >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
 
     for (u32 item = blockIdx.x; item < a.nitems; item += gridDim.x) {
-        const u32 blk = item & ((1u << a.s0) - 1);
-        const u32 limb = limb_of(item);
-        u64 *const g = a.data + (((size_t)limb << a.s0) + blk) * NS;  // uniform
+        const bool lift = LIFT && !INV && item >= a.lift_first;
+        const u32 item_l = lift ? item - a.lift_first : item;
+        const u32 blk = item_l & ((1u << a.s0) - 1);
+        const u32 limb = lift ? item_l >> a.s0 : limb_of(item);
+        u64 *const g = (lift ? a.data2 : a.data) + (((size_t)limb << a.s0) + blk) * NS;  // uniform
         const u32 mod = a.mod_base + limb % a.mod_count;
         const u64 q = a.dc->mod[mod].q;
         const u64 q2 = 2 * q, q4 = 4 * q;
@@ -253,11 +261,49 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
             NTT16_STAMP(0);
             NTT16_PASS_PRIO(3);
             // ---- pass 1: rows r = 0..7 (bits 12..10) of the column pair -------------------------------------------------
+            if (lift) {
+                // equal-width primes (q_i < 2 q_j for every pair: the host checks): a conditional subtraction reduces a residue
+                // mod q_i into q_j, and residues above q_i / 2 are corrected by q_i mod q_j (centred lift, kernels_pie.hip)
+                const u32 LL = a.lift_L, li = (limb / LL) % LL, lj = limb % LL;
+                const u64 *src = a.lift_src + (size_t)(limb / (LL * LL)) * a.lift_stride + (size_t)li * a.N;
+                const u64 qh = a.dc->mod[li].q / 2, qq = a.dc->qi_modqj[li][lj];
+                auto lift1 = [&](u64 v) -> u64 {
+                    u64 r = v >= q ? v - q : v;
+                    const u64 c = v > qh ? qq : 0;
+                    r = r >= c ? r - c : r + q - c;
+                    return r;
+                };
+                if (a.s0 == 1) {
+                    // two folded slices per limb: the outermost stage (u, v) -> (u + v psi^{N/2}, u - v psi^{N/2}) is one more
+                    // butterfly, and this slice keeps its half (kernels_pie.hip fold_store does the same for the other kernels)
+                    u64x2 fw;
+                    fw.x = a.dc->fold_w[lj];
+                    fw.y = a.dc->fold_w_sh[lj] >> 1;
+                    const Tw t = make_tw(fw);
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const u64x2 v = *reinterpret_cast<const u64x2 *>(g + 1024 * r + voff);
-                x[2 * r] = v.x;
-                x[2 * r + 1] = v.y;
+                    for (int r = 0; r < 8; r++) {
+                        const u64x2 u = *reinterpret_cast<const u64x2 *>(src + 1024 * r + voff);
+                        const u64x2 v = *reinterpret_cast<const u64x2 *>(src + NS + 1024 * r + voff);
+                        u64 u0 = lift1(u.x), u1 = lift1(u.y), v0 = lift1(v.x), v1 = lift1(v.y);
+                        bfly2<false, true>(u0, v0, t, u1, v1, t, mc);
+                        x[2 * r] = blk ? v0 : u0;
+                        x[2 * r + 1] = blk ? v1 : u1;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        const u64x2 u = *reinterpret_cast<const u64x2 *>(src + 1024 * r + voff);
+                        x[2 * r] = lift1(u.x);
+                        x[2 * r + 1] = lift1(u.y);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const u64x2 v = *reinterpret_cast<const u64x2 *>(g + 1024 * r + voff);
+                    x[2 * r] = v.x;
+                    x[2 * r + 1] = v.y;
+                }
             }
 #pragma unroll
             for (int s = 0; s < 3; s++) {
@@ -365,7 +411,7 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
                 bfly2<false, false>(x[k], x[k + 1], make_tw(t12[k >> 1]), x[k + 2], x[k + 3], make_tw(t12[(k >> 1) + 1]), mc);
             NTT16_STAMP(7);
             // ---- lane-ordered store -------------------------------------------------------------------------------------------
-            const bool lazy = (a.flags & F_LAZY_OUT) != 0;
+            const bool lazy = (a.flags & F_LAZY_OUT) != 0 && !lift;  // the key-switch MAC splits canonical digits into 30-bit halves
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 u64 r0 = x[2 * j], r1 = x[2 * j + 1];
@@ -385,6 +431,7 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
             NTT16_STAMP(8);
         } else {
             // ---- input: 16 contiguous coefficients per thread -------------------------------------------------------------
+            NTT16_PASS_PRIO(3);
             NTT16_LOAD4(t12, 4, 8);
             if (a.flags & F_STD_IN) {
                 // standard order: coalesced rows through LDS
@@ -447,6 +494,7 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
             }
             wave_sync();
             // ---- pass 3': stages 10..7 -----------------------------------------------------------------------------------------
+            NTT16_PASS_PRIO(2);
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = p3[4 * k + 2 * (k >> 3)];
             NTT16_LOAD3(t9, 2);
@@ -477,6 +525,7 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
             for (int k = 0; k < 16; k++) p3[4 * k + 2 * (k >> 3)] = x[k];
             wave_sync();
             // ---- pass 2': stages 6..3 ------------------------------------------------------------------------------------------
+            NTT16_PASS_PRIO(1);
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = p2[68 * k];
 #pragma unroll
@@ -494,6 +543,7 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
             for (int k = 0; k < 16; k++) p2[68 * k] = x[k];
             __syncthreads();
             // ---- pass 1': stages 2..0, stored straight to HBM ------------------------------------------------------------------
+            NTT16_PASS_PRIO(0);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const u64x2 v = *reinterpret_cast<const u64x2 *>(p1 + 1088 * r);

@@ -283,16 +283,17 @@ static bool xq_reuse(const piehip_ctx *h) { return h->sigma_on && ntt_supports_e
 // ciphertexts at w.d01, optionally multiplied by mask plaintexts: out[nb][2][L][N]
 // sigma: w.d01 and the digits are in lane order, key/mask are lane-ordered copies, out is written in standard order
 static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, const u64 *mask, u64 *out, bool sigma = false,
-                              bool fold = false, size_t key_stride = 0, u32 key_group = 1, bool out_is_result = false)
+                              bool fold = false, size_t key_stride = 0, u32 key_group = 1, bool out_is_result = false,
+                              bool digits_ready = false)
 {
     const u32 N = h->hp.N, L = h->hp.L;
     const size_t LN = h->LN();
     const double W = 8.0 * N;
     set_small_moduli(h->small_moduli);
-    bool fused = false;
+    bool fused = digits_ready;  // the caller's transform launch of d01 also lifted and transformed the digits
     // digit lift inside the transform's load phase (the 32-coefficient kernel; contexts whose lane order is the 16-coefficient
     // kernel's take the digits kernel + transform below)
-    if (h->sigma_on && h->d_twc && h->hp.logN <= 14 && !(sigma && ntt16_applies(h->plan, fold && h->fold_on))) {
+    if (!fused && h->sigma_on && h->d_twc && h->hp.logN <= 14 && !(sigma && ntt16_applies(h->plan, fold && h->fold_on))) {
         ProfScope ps(h, PIEHIP_K_NTT_FWD, 16.0 * N * nb * L * L);
         fused = launch_ntt_digits(h->plan, w.d2c, w.dig, nb, L, sigma && h->sigma_on, fold && h->fold_on, h->stream);
     }
@@ -349,12 +350,20 @@ static void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const 
             ProfScope ps(h, PIEHIP_K_SCALE, W * nb * (3.0 * M + 3.0 * L));
             launch_scale_round(h->d_dc, N, L, w.dqp, nb, w.d01, 2 * LN, w.d2c, LN, h->stream, h->fold_on, false);
         }
+        bool digits_ready = false;
         {
             NttExtra ex;
             ex.lazy_out = true;  // the key-switch MAC adds d01 into its accumulator before reducing
-            ntt(h, w.d01, nb * 2 * L, 0, L, false, true, true, &ex);
+            if (h->sigma_on && h->small_moduli && ntt16_applies(h->plan, h->fold_on)) {
+                // one launch for both forward transforms in front of the key-switch MAC: d0, d1 and the L * L digits of d2
+                // (equal-width primes only: the kernel's lift is a conditional subtraction)
+                ProfScope ps(h, PIEHIP_K_NTT_FWD, 16.0 * N * nb * (2.0 * L + (double)L * L));
+                Ntt16Digits dg = {w.d2c, LN, w.dig, nb, L};
+                digits_ready = launch_ntt16(h->plan, h->fold_on, w.d01, nb * 2 * L, 0, L, false, true, h->stream, &ex, &dg);
+            }
+            if (!digits_ready) ntt(h, w.d01, nb * 2 * L, 0, L, false, true, true, &ex);
         }
-        enqueue_keyswitch(h, w, nb, h->sigma_on ? h->d_evk_sigma : h->d_evk, mask, out, true, true, 0, 1, out_is_result);
+        enqueue_keyswitch(h, w, nb, h->sigma_on ? h->d_evk_sigma : h->d_evk, mask, out, true, true, 0, 1, out_is_result, digits_ready);
     } else {
         {
             ProfScope ps(h, PIEHIP_K_SCALE, W * nb * (3.0 * M + 3.0 * L));
