@@ -20,6 +20,21 @@ def _out(shape, dtype):
     return a
 
 
+PLAINTEXT_MODULI = {16: 65537, 32: 4296540161, 40: 1099579260929, 48: 281474981953537}
+
+
+def select_parameters(bitSize, eachCuckooTableSize):
+    """The reference client's scheme parameters (BatchedFHEPSIClient.cpp:22-57,72-78): plaintext modulus by item bit size
+    (ValueError as the reference's invalid_argument otherwise), multiplicative depth 3 / 5 / 10 by inner table size, ring
+    dimension 16384.  The number of 60-bit primes OpenFHE derives from the depth is not in the reference tree
+    [OFHE-UNVERIFIED]: depth 3 with the 33-bit modulus is the 4-prime chain BASELINE.json names; deeper settings take one
+    prime per level plus one."""
+    if bitSize not in PLAINTEXT_MODULI:
+        raise ValueError("Error: FHE can only support bit sizes 16 or 32.")
+    depth = 3 if eachCuckooTableSize < 500 else (5 if eachCuckooTableSize < 5000 else 10)
+    return dict(N=16384, t=PLAINTEXT_MODULI[bitSize], depth=depth, L=depth + 1)
+
+
 class BatchedFHEPSIClient:
     """Mirror of BatchedFHEPSIClient (BatchedFHEPSIClient.cpp:14-193): runSetUpPhase, runOfflinePhase,
     the online-phase result extraction.  No TCP: the caller moves the arrays."""

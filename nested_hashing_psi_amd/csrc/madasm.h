@@ -1,25 +1,15 @@
 // madasm.h -- v_mad_u64_u32 based multiply-accumulate helpers (device only, gfx950).
-//
-// v_mad_u64_u32 (32x32+64 -> 64) issues at twice the rate of v_mul_lo_u32 / v_mul_hi_u32 on gfx950
-// (tools/microbench.hip: 5.1 vs 9 cycles per wave64 op per SIMD), and hipcc narrows every 64-bit product
-// whose high half is unused to v_mul_lo_u32; inline asm keeps the hot loops on the mad.
 #pragma once
 #include "modarith.h"
 
 namespace piehip {
 
-__device__ __forceinline__ u64 mad_u(u32 a, u32 b, u64 c)
-{
-    u64 d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ u64 mul_u(u32 a, u32 b)
-{
-    u64 d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=&v"(d), "=s"(carry) : "v"(a), "v"(b));
-    return d;
-}
+// 32 x 32 + 64 -> 64.  Plain C++: hipcc selects v_mad_u64_u32 whenever all 64 result bits are live (they are in every
+// accumulator below), schedules it with exact hazard knowledge and takes uniform operands from SGPRs.  (An earlier version
+// issued the instruction through inline asm: every asm statement costs an s_nop and early-clobber copies on gfx950, and the
+// premise -- v_mul_lo_u32 at half the rate of the mad -- does not hold: tools/microbench_ops.hip measures 4.1 vs 4.2 cycles.)
+__device__ __forceinline__ u64 mad_u(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
+__device__ __forceinline__ u64 mul_u(u32 a, u32 b) { return (u64)a * b; }
 
 // Carry-free accumulation of products of residues < 2^60: operands are split into 30-bit halves and the
 // three product columns (2^0, 2^30, 2^60) are summed in separate 64-bit words.  Every partial product is

@@ -116,3 +116,14 @@ def test_cpp_server_harness_compiles(built, tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "server_main.cpp"),
                            "-L" + libdir, "-lpiehip", "-Wl,-rpath," + libdir])
     assert subprocess.call([exe]) == 2  # usage error: no arguments
+
+
+def test_client_parameter_selection_follows_the_reference():
+    """BatchedFHEPSIClient.cpp:22-57: plaintext modulus by bit size, depth by inner table size, ring 16384"""
+    import pytest
+    from nested_hashing_psi_amd.client import select_parameters
+    assert select_parameters(32, 14) == dict(N=16384, t=4296540161, depth=3, L=4)
+    assert select_parameters(16, 499)["t"] == 65537 and select_parameters(16, 500)["depth"] == 5
+    assert select_parameters(48, 5000)["depth"] == 10 and select_parameters(40, 1)["t"] == 1099579260929
+    with pytest.raises(ValueError):
+        select_parameters(24, 10)
