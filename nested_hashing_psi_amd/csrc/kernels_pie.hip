@@ -89,11 +89,8 @@ __global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *__restric
 
 // Same work with carry-free column accumulators on v_mad_u64_u32 (madasm.h): the 128-bit form above is bound by
 // its 64x64->128 multiplies (46 SIMD cycles each, 3.9 TB/s at C3), this one by HBM.  Needs every modulus
-// < 2^60 and E <= COLACC_MAX_TOTAL (one carry sweep after 8 terms keeps the columns from overflowing).
-#ifndef STAGE_A_PREFETCH
-#define STAGE_A_PREFETCH 1
-#endif
-template <int BPT, int CPT>
+// < 2^60 (a carry sweep every 8 terms keeps the low columns from overflowing, a reduction every 15 the top one).
+template <int BPT, int CPT, int DEPTH = (CPT == 1 ? 2 : 1)>
 __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
                                                           const u64 *__restrict__ idx, const u64 *__restrict__ minus,
                                                           const u64 *__restrict__ db, u64 *__restrict__ acc, u32 bstride, u32 h0)
@@ -109,7 +106,6 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
     const u64 *pi = idx + ((size_t)h * E) * 2 * LN + (size_t)l * N + n;
     const u64 *pd = db + (((size_t)h * bstride + beta0) * E) * LN + (size_t)l * N + n;  // db is [K][bstride][E][L][N]
     const size_t bin_stride = (size_t)E * LN;
-    constexpr bool PREFETCH = STAGE_A_PREFETCH != 0;
     ColAcc a[BPT][2][CPT];
 #pragma unroll
     for (int t = 0; t < BPT; t++)
@@ -119,7 +115,7 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
             for (int e = 0; e < CPT; e++) a[t][c][e] = ColAcc{0, 0, 0};
     // operands of term j: loaded one term ahead (2 + BPT independent streams per thread; without the prefetch a wave
     // alternates between waiting for them and ~110 mads, and three waves per SIMD do not cover the HBM latency)
-    u64 iv[2][CPT], dv[BPT][CPT], niv[2][CPT], ndv[BPT][CPT];
+    u64 iv[2][CPT], dv[BPT][CPT];
     auto load_term = [&](u32 j, u64 (&vi)[2][CPT], u64 (&vd)[BPT][CPT]) {
         if (CPT == 2) {
             const u64x2 i0 = *reinterpret_cast<const u64x2 *>(pi + (size_t)j * 2 * LN);
@@ -137,17 +133,33 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
             for (int t = 0; t < BPT; t++) vd[t][0] = pd[(size_t)t * bin_stride + (size_t)j * LN];
         }
     };
-    load_term(0, niv, ndv);
+    // DEPTH terms in flight behind the one being accumulated.  A term is 2 + BPT loads and a few hundred cycles of arithmetic
+    // against microseconds of HBM latency: with the 14 bin layers of the headline workload three resident waves per SIMD and
+    // two terms in flight cover it; one rank's share of a sharded server launches two waves per SIMD or fewer, runs at one
+    // memory latency per DEPTH terms, and gets four (launch_stage_a picks; the extra buffers cost resident waves it does not
+    // have anyway).  Two coefficients per thread: one term ahead (a second buffer would cost a resident wave).
+    u64 qiv[DEPTH][2][CPT], qdv[DEPTH][BPT][CPT];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if ((u32)d < E) load_term(d, qiv[d], qdv[d]);
     for (u32 j = 0; j < E; j++) {
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
-            for (int e = 0; e < CPT; e++) iv[c][e] = niv[c][e];
+            for (int e = 0; e < CPT; e++) {
+                iv[c][e] = qiv[0][c][e];
+#pragma unroll
+                for (int d = 0; d + 1 < DEPTH; d++) qiv[d][c][e] = qiv[d + 1][c][e];
+            }
 #pragma unroll
         for (int t = 0; t < BPT; t++)
 #pragma unroll
-            for (int e = 0; e < CPT; e++) dv[t][e] = ndv[t][e];
-        if (PREFETCH && j + 1 < E) load_term(j + 1, niv, ndv);
+            for (int e = 0; e < CPT; e++) {
+                dv[t][e] = qdv[0][t][e];
+#pragma unroll
+                for (int d = 0; d + 1 < DEPTH; d++) qdv[d][t][e] = qdv[d + 1][t][e];
+            }
+        if (j + DEPTH < E) load_term(j + DEPTH, qiv[DEPTH - 1], qdv[DEPTH - 1]);
         Split30 is[2][CPT];
 #pragma unroll
         for (int c = 0; c < 2; c++)
@@ -161,7 +173,6 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
                 colacc_mac(a[t][0][e], is[0][e], ds);
                 colacc_mac(a[t][1][e], is[1][e], ds);
             }
-        if (!PREFETCH && j + 1 < E) load_term(j + 1, niv, ndv);
         if ((j % COLACC_MAX_TERMS) == COLACC_MAX_TERMS - 1 && j + 1 < E) {  // more terms follow: make room in the low columns
 #pragma unroll
             for (int t = 0; t < BPT; t++)
@@ -169,6 +180,17 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
                 for (int c = 0; c < 2; c++)
 #pragma unroll
                     for (int e = 0; e < CPT; e++) colacc_carry(a[t][c][e]);
+        }
+        if ((j % COLACC_MAX_TOTAL) == COLACC_MAX_TOTAL - 1 && j + 1 < E) {  // the top column is full: reduce and start over
+#pragma unroll
+            for (int t = 0; t < BPT; t++)
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int e = 0; e < CPT; e++) {
+                        const u64 r = reduce128(colacc_value(a[t][c][e]), m);
+                        a[t][c][e] = ColAcc{r & 0x3FFFFFFFull, r >> 30, 0};
+                    }
         }
     }
 #pragma unroll
@@ -182,27 +204,22 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
     }
 }
 
-void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
-                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride, u32 h0, u32 hn)
+// one launch over b bin layers whose count is a multiple of the per-thread layer count `bpt`
+static void launch_stage_a_uniform(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
+                                   const u64 *db, u64 *acc, hipStream_t st, bool mad, u32 bstride, u32 h0, u32 hn, int bpt)
 {
-    if (!bstride) bstride = b;
-    if (!hn) hn = K - h0;
-    // bin layers per thread: the largest divisor of b that keeps the accumulators in registers
-    const bool mad = small_moduli && E <= COLACC_MAX_TOTAL;
-    const int cap = mad ? 7 : 8;
-    int bpt = 1;
-    for (int c = cap; c >= 1; c--)
-        if (b % c == 0) {
-            bpt = c;
-            break;
-        }
     // the mad kernel keeps 6 accumulator registers per (layer, component, coefficient): above 4 layers per
     // thread it handles one coefficient per thread (8-byte lanes) to stay at >= 2 waves per SIMD
-    const int cpt = (mad && bpt > 4) ? 1 : 2;
+    int cpt = (mad && bpt > 4) ? 1 : 2;
+    // few workgroups (one rank's share): one coefficient per thread doubles them, and four terms in flight per thread
+    // replace the memory-level parallelism that resident waves do not provide
+    const bool sparse = mad && (size_t)(N / TPB) * L * hn * (b / bpt) < 1024;
+    if (sparse) cpt = 1;
     dim3 grid((N / cpt + TPB - 1) / TPB, L, hn * (b / bpt));
 #define SA(B_)                                                                                                       \
     do {                                                                                                             \
-        if (mad && cpt == 1) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 1>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0); \
+        if (sparse) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 1, 4>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0); \
+        else if (mad && cpt == 1) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 1>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0); \
         else if (mad) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 2>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0); \
         else hipLaunchKernelGGL(stage_a_kernel<B_>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0);  \
     } while (0)
@@ -217,6 +234,35 @@ void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, cons
         default: SA(1); break;
     }
 #undef SA
+}
+
+void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
+                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride, u32 h0, u32 hn)
+{
+    if (!bstride) bstride = b;
+    if (!hn) hn = K - h0;
+    const bool mad = small_moduli;
+    const u32 cap = mad ? 7 : 8;
+    // Bin layers per thread: a thread re-reads the two index-ciphertext limbs once per group of layers, so groups should be
+    // as large as the accumulators allow.  A divisor of b in [4, cap] gives one uniform launch; otherwise (b = 17, 23, ...:
+    // one queue's share of an odd split) groups of `cap` layers plus one launch for the remainder -- never one layer per
+    // thread, which read the index matrix b times.
+    u32 bpt = 0;
+    for (u32 c = cap; c >= 4; c--)
+        if (b % c == 0) {
+            bpt = c;
+            break;
+        }
+    if (b <= cap) bpt = b;
+    const size_t LN = (size_t)L * N;
+    if (bpt) {
+        launch_stage_a_uniform(dc, N, L, K, b, E, idx, minus, db, acc, st, mad, bstride, h0, hn, (int)bpt);
+        return;
+    }
+    const u32 full = (b / cap) * cap, rest = b - full;
+    launch_stage_a_uniform(dc, N, L, K, full, E, idx, minus, db, acc, st, mad, bstride, h0, hn, (int)cap);
+    launch_stage_a_uniform(dc, N, L, K, rest, E, idx, minus, db + (size_t)full * E * LN, acc + (size_t)full * K * 2 * LN, st, mad,
+                           bstride, h0, hn, (int)rest);
 }
 
 // ---------------------------------------------------------------------------------------------

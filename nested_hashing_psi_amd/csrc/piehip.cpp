@@ -1005,6 +1005,16 @@ int piehip_set_minus_device(piehip_handle h, const void *d_minus)
     return PIEHIP_OK;
 }
 
+// Queues of a run().  The default is two when the handle evaluates enough bin layers to fill the chip twice over; below that
+// every launch is bound by its own latency, a second queue only interleaves two latency-bound chains on the same CUs, and one
+// queue is faster (measured at the C3 ring: 2 layers 115 vs 146 us, 5 layers of the E = 40 row 217 vs 239 us, 7 layers even).
+static u32 run_queue_count(const piehip_ctx *h)
+{
+    const size_t nq = h->side_streams.size();
+    const u32 want = h->run_streams ? h->run_streams : (h->b >= 8 ? 2u : 1u);
+    return (u32)std::min<size_t>(want, std::min<size_t>(nq, h->b));
+}
+
 // bin layers of queue group g of ng.  Two groups take 4/7 and 3/7 of the layers: measured 3.5 % faster than equal halves at
 // b = 14 (8 + 6: the ragged transform launches of the two queues fit the workgroup slots better than 7 + 7).
 static u32 run_group_size(u32 b, u32 ng, u32 g)
@@ -1090,8 +1100,7 @@ int piehip_run_into(piehip_handle h, void *d_results)
     //     before this call (it may still be reading the result buffer of an earlier run);
     //   * the handle's stream joins the queues lazily, in the next entry point that is not a run (NEED / piehip_join),
     //     so back-to-back runs of one query batch keep every queue busy across run boundaries.
-    const size_t nq = h->side_streams.size();
-    const u32 ng = (u32)std::min<size_t>(h->run_streams ? h->run_streams : nq, std::min<size_t>(nq, b));
+    const u32 ng = run_queue_count(h);
     if (h->use_graph && !h->profiling && !h->row_events) {
         // One graph launch instead of ~13 kernel launches and 2 event operations per queue group: the same two chains, forked
         // from and joined back to the handle's stream inside the graph (so consecutive runs do not overlap each other, which
@@ -1248,8 +1257,7 @@ int piehip_run_host(piehip_handle h, const uint64_t *idx, const uint64_t *minus,
     if (results) {
         // every queue group's slice of the result list leaves as soon as that group is done
         if (h->pending_join) {
-            const size_t nq = h->side_streams.size();
-            const u32 ng = (u32)std::min<size_t>(h->run_streams ? h->run_streams : nq, std::min<size_t>(nq, h->b));
+            const u32 ng = run_queue_count(h);
             u32 b0 = 0;
             for (u32 g = 0; g < ng; g++) {
                 const u32 nb = run_group_size(h->b, ng, g);
