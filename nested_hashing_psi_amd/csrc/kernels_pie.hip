@@ -90,117 +90,74 @@ __global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *__restric
 // Same work with carry-free column accumulators on v_mad_u64_u32 (madasm.h): the 128-bit form above is bound by
 // its 64x64->128 multiplies (46 SIMD cycles each, 3.9 TB/s at C3), this one by HBM.  Needs every modulus
 // < 2^60 (a carry sweep every 8 terms keeps the low columns from overflowing, a reduction every 15 the top one).
-template <int BPT, int CPT, int DEPTH = (CPT == 1 ? 2 : 1)>
+// One coefficient per thread and SA_DEPTH terms in flight behind the one being accumulated: a term is 2 + BPT loads of
+// 8 bytes per lane against microseconds of HBM latency and ~80 instructions of arithmetic.  tools/microbench_stage_a.hip
+// runs this kernel over a rotation of databases (every launch from HBM): 49 us for the 196 MiB of the headline workload
+// with seven layers per thread (168 registers, three waves per SIMD), the same with 16-byte lanes and one term ahead, 63 us
+// when it is forced to four waves per SIMD (spills) -- and 35 us for a plain read of the same bytes.
+static const int SA_DEPTH = 4;
+template <int BPT>
 __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
                                                           const u64 *__restrict__ idx, const u64 *__restrict__ minus,
                                                           const u64 *__restrict__ db, u64 *__restrict__ acc, u32 bstride, u32 h0)
 {
-    // CPT coefficients per thread: 2 -> 16-byte lanes; 1 -> 8-byte lanes, half the accumulator registers
-    const u32 n = CPT * (blockIdx.x * TPB + threadIdx.x);
+    const u32 nl = threadIdx.x;  // lane part of the coefficient index: every stream is a uniform base plus this
+    const u32 n = blockIdx.x * TPB + nl;
     const u32 l = blockIdx.y;
     const u32 groups = b / BPT;
     const u32 h = h0 + blockIdx.z / groups, beta0 = (blockIdx.z % groups) * BPT;
     if (n >= N) return;
     const Mod m = dc->mod[l];
     const size_t LN = (size_t)L * N;
-    const u64 *pi = idx + ((size_t)h * E) * 2 * LN + (size_t)l * N + n;
-    const u64 *pd = db + (((size_t)h * bstride + beta0) * E) * LN + (size_t)l * N + n;  // db is [K][bstride][E][L][N]
+    // uniform stream bases (scalar registers where the compiler can; the loads take base + lane offset)
+    const u64 *pi = idx + ((size_t)h * E) * 2 * LN + (size_t)l * N + blockIdx.x * TPB;
+    const u64 *pd = db + (((size_t)h * bstride + beta0) * E) * LN + (size_t)l * N + blockIdx.x * TPB;  // db is [K][bstride][E][L][N]
     const size_t bin_stride = (size_t)E * LN;
-    ColAcc a[BPT][2][CPT];
+    ColAcc a[BPT][2];
 #pragma unroll
-    for (int t = 0; t < BPT; t++)
+    for (int t = 0; t < BPT; t++) a[t][0] = a[t][1] = ColAcc{0, 0, 0};
+    auto load_term = [&](u32 j, u64 (&vi)[2], u64 (&vd)[BPT]) {
+        const u64 *pij = pi + (size_t)j * 2 * LN, *pdj = pd + (size_t)j * LN;
+        vi[0] = pij[nl];
+        vi[1] = (pij + LN)[nl];
 #pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int e = 0; e < CPT; e++) a[t][c][e] = ColAcc{0, 0, 0};
-    // operands of term j: loaded one term ahead (2 + BPT independent streams per thread; without the prefetch a wave
-    // alternates between waiting for them and ~110 mads, and three waves per SIMD do not cover the HBM latency)
-    u64 iv[2][CPT], dv[BPT][CPT];
-    auto load_term = [&](u32 j, u64 (&vi)[2][CPT], u64 (&vd)[BPT][CPT]) {
-        if (CPT == 2) {
-            const u64x2 i0 = *reinterpret_cast<const u64x2 *>(pi + (size_t)j * 2 * LN);
-            const u64x2 i1 = *reinterpret_cast<const u64x2 *>(pi + (size_t)j * 2 * LN + LN);
-            vi[0][0] = i0.x, vi[0][CPT - 1] = i0.y, vi[1][0] = i1.x, vi[1][CPT - 1] = i1.y;
-#pragma unroll
-            for (int t = 0; t < BPT; t++) {
-                const u64x2 d = *reinterpret_cast<const u64x2 *>(pd + (size_t)t * bin_stride + (size_t)j * LN);
-                vd[t][0] = d.x, vd[t][CPT - 1] = d.y;
-            }
-        } else {
-            vi[0][0] = pi[(size_t)j * 2 * LN];
-            vi[1][0] = pi[(size_t)j * 2 * LN + LN];
-#pragma unroll
-            for (int t = 0; t < BPT; t++) vd[t][0] = pd[(size_t)t * bin_stride + (size_t)j * LN];
-        }
+        for (int t = 0; t < BPT; t++) vd[t] = (pdj + (size_t)t * bin_stride)[nl];
     };
-    // DEPTH terms in flight behind the one being accumulated.  A term is 2 + BPT loads and a few hundred cycles of arithmetic
-    // against microseconds of HBM latency: with the 14 bin layers of the headline workload three resident waves per SIMD and
-    // two terms in flight cover it; one rank's share of a sharded server launches two waves per SIMD or fewer, runs at one
-    // memory latency per DEPTH terms, and gets four (launch_stage_a picks; the extra buffers cost resident waves it does not
-    // have anyway).  Two coefficients per thread: one term ahead (a second buffer would cost a resident wave).
-    u64 qiv[DEPTH][2][CPT], qdv[DEPTH][BPT][CPT];
+    // a ring of SA_DEPTH term buffers; the term loop is unrolled SA_DEPTH times so that the ring needs no register moves
+    u64 qiv[SA_DEPTH][2], qdv[SA_DEPTH][BPT];
 #pragma unroll
-    for (int d = 0; d < DEPTH; d++)
+    for (int d = 0; d < SA_DEPTH; d++)
         if ((u32)d < E) load_term(d, qiv[d], qdv[d]);
-    for (u32 j = 0; j < E; j++) {
+    auto term = [&](u32 j, u64 (&vi)[2], u64 (&vd)[BPT]) {
+        const Split30 i0 = split30(vi[0]), i1 = split30(vi[1]);
 #pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int e = 0; e < CPT; e++) {
-                iv[c][e] = qiv[0][c][e];
-#pragma unroll
-                for (int d = 0; d + 1 < DEPTH; d++) qiv[d][c][e] = qiv[d + 1][c][e];
-            }
-#pragma unroll
-        for (int t = 0; t < BPT; t++)
-#pragma unroll
-            for (int e = 0; e < CPT; e++) {
-                dv[t][e] = qdv[0][t][e];
-#pragma unroll
-                for (int d = 0; d + 1 < DEPTH; d++) qdv[d][t][e] = qdv[d + 1][t][e];
-            }
-        if (j + DEPTH < E) load_term(j + DEPTH, qiv[DEPTH - 1], qdv[DEPTH - 1]);
-        Split30 is[2][CPT];
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int e = 0; e < CPT; e++) is[c][e] = split30(iv[c][e]);
-#pragma unroll
-        for (int t = 0; t < BPT; t++)
-#pragma unroll
-            for (int e = 0; e < CPT; e++) {
-                const Split30 ds = split30(dv[t][e]);
-                colacc_mac(a[t][0][e], is[0][e], ds);
-                colacc_mac(a[t][1][e], is[1][e], ds);
-            }
+        for (int t = 0; t < BPT; t++) colacc_mac2(a[t][0], a[t][1], i0, i1, vd[t]);
+        if (j + SA_DEPTH < E) load_term(j + SA_DEPTH, vi, vd);  // refill this ring slot (the other slots are in flight)
         if ((j % COLACC_MAX_TERMS) == COLACC_MAX_TERMS - 1 && j + 1 < E) {  // more terms follow: make room in the low columns
 #pragma unroll
-            for (int t = 0; t < BPT; t++)
-#pragma unroll
-                for (int c = 0; c < 2; c++)
-#pragma unroll
-                    for (int e = 0; e < CPT; e++) colacc_carry(a[t][c][e]);
+            for (int t = 0; t < BPT; t++) colacc_carry(a[t][0]), colacc_carry(a[t][1]);
         }
         if ((j % COLACC_MAX_TOTAL) == COLACC_MAX_TOTAL - 1 && j + 1 < E) {  // the top column is full: reduce and start over
 #pragma unroll
             for (int t = 0; t < BPT; t++)
 #pragma unroll
-                for (int c = 0; c < 2; c++)
-#pragma unroll
-                    for (int e = 0; e < CPT; e++) {
-                        const u64 r = reduce128(colacc_value(a[t][c][e]), m);
-                        a[t][c][e] = ColAcc{r & 0x3FFFFFFFull, r >> 30, 0};
-                    }
+                for (int c = 0; c < 2; c++) {
+                    const u64 r = reduce124(colacc_value(a[t][c]), m);
+                    a[t][c] = ColAcc{r & 0x3FFFFFFFull, r >> 30, 0};
+                }
         }
+    };
+    for (u32 j = 0; j < E; j += SA_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < SA_DEPTH; d++)
+            if (j + d < E) term(j + d, qiv[d], qdv[d]);
     }
 #pragma unroll
     for (int t = 0; t < BPT; t++) {
         u64 *po = acc + (((size_t)(beta0 + t) * K + h) * 2) * LN + (size_t)l * N + n;
 #pragma unroll
         for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int e = 0; e < CPT; e++)
-                po[(size_t)c * LN + e] = addmod(reduce128(colacc_value(a[t][c][e]), m), minus[(size_t)c * LN + (size_t)l * N + n + e], m.q);
+            po[(size_t)c * LN] = addmod(reduce124(colacc_value(a[t][c]), m), minus[(size_t)c * LN + (size_t)l * N + n], m.q);
     }
 }
 
@@ -208,19 +165,11 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
 static void launch_stage_a_uniform(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
                                    const u64 *db, u64 *acc, hipStream_t st, bool mad, u32 bstride, u32 h0, u32 hn, int bpt)
 {
-    // the mad kernel keeps 6 accumulator registers per (layer, component, coefficient): above 4 layers per
-    // thread it handles one coefficient per thread (8-byte lanes) to stay at >= 2 waves per SIMD
-    int cpt = (mad && bpt > 4) ? 1 : 2;
-    // few workgroups (one rank's share): one coefficient per thread doubles them, and four terms in flight per thread
-    // replace the memory-level parallelism that resident waves do not provide
-    const bool sparse = mad && (size_t)(N / TPB) * L * hn * (b / bpt) < 1024;
-    if (sparse) cpt = 1;
+    const int cpt = mad ? 1 : 2;
     dim3 grid((N / cpt + TPB - 1) / TPB, L, hn * (b / bpt));
 #define SA(B_)                                                                                                       \
     do {                                                                                                             \
-        if (sparse) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 1, 4>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0); \
-        else if (mad && cpt == 1) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 1>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0); \
-        else if (mad) hipLaunchKernelGGL((stage_a_mad_kernel<B_, 2>), grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0); \
+        if (mad) hipLaunchKernelGGL(stage_a_mad_kernel<B_>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0); \
         else hipLaunchKernelGGL(stage_a_kernel<B_>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0);  \
     } while (0)
     switch (bpt) {

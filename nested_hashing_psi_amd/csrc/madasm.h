@@ -36,6 +36,27 @@ __device__ __forceinline__ void colacc_mac(ColAcc &a, Split30 x, Split30 y)
     a.c1 = mad_u(x.hi, y.lo, a.c1);
     a.c2 = mad_u(x.hi, y.hi, a.c2);
 }
+// Two accumulators (the two components of an index ciphertext) take the same database word d < 2^60: split d and issue the
+// eight multiply-adds as ONE instruction block.  Left to the compiler, the sums are reassociated into v_mad_u64_u32 ..., 0
+// plus a 64-bit add per column (98 instructions for 7 words instead of 56) and the halves of d live in extra registers.
+__device__ __forceinline__ void colacc_mac2(ColAcc &a, ColAcc &b, Split30 x0, Split30 x1, u64 d)
+{
+    u32 dl, dh;
+    asm("v_and_b32 %[dl], 0x3fffffff, %[d0]\n\t"
+        "v_alignbit_b32 %[dh], %[d1], %[d0], 30\n\t"
+        "v_mad_u64_u32 %[a0], vcc, %[x0l], %[dl], %[a0]\n\t"
+        "v_mad_u64_u32 %[a1], vcc, %[x0l], %[dh], %[a1]\n\t"
+        "v_mad_u64_u32 %[b0], vcc, %[x1l], %[dl], %[b0]\n\t"
+        "v_mad_u64_u32 %[b1], vcc, %[x1l], %[dh], %[b1]\n\t"
+        "v_mad_u64_u32 %[a2], vcc, %[x0h], %[dh], %[a2]\n\t"
+        "v_mad_u64_u32 %[b2], vcc, %[x1h], %[dh], %[b2]\n\t"
+        "v_mad_u64_u32 %[a1], vcc, %[x0h], %[dl], %[a1]\n\t"
+        "v_mad_u64_u32 %[b1], vcc, %[x1h], %[dl], %[b1]\n\t"
+        : [a0] "+v"(a.c0), [a1] "+v"(a.c1), [a2] "+v"(a.c2), [b0] "+v"(b.c0), [b1] "+v"(b.c1), [b2] "+v"(b.c2), [dl] "=&v"(dl),
+          [dh] "=&v"(dh)
+        : [d0] "v"((u32)d), [d1] "v"((u32)(d >> 32)), [x0l] "v"(x0.lo), [x0h] "v"(x0.hi), [x1l] "v"(x1.lo), [x1h] "v"(x1.hi)
+        : "vcc");
+}
 // push the overflow of the two low columns upwards (value unchanged): after it c0, c1 < 2^30, so another
 // COLACC_MAX_TERMS terms fit; the top column then holds up to 15 terms' worth before it overflows
 static const u32 COLACC_MAX_TOTAL = 15;

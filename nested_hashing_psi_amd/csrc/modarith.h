@@ -89,6 +89,19 @@ PH_HD u64 reduce123(U128 z, const Mod &m)
     r = r >= m.q ? r - m.q : r;
     return r;
 }
+// z < 2^124 (15 products of residues < 2^60, plus a residue): the same with one bit less of z.  t = floor(floor(z / 2^60)
+// mu / 2^64) lies in (z / 2q - 3, z / 2q], so z - 2 t q is in [0, 7q) < 2^63: three conditional subtractions.
+PH_HD u64 reduce124(U128 z, const Mod &m)
+{
+    const u64 mu = (m.r1 << 59) | (m.r0 >> 5);
+    const u64 zh = (z.hi << 4) | (z.lo >> 60);
+    const u64 qhat = mulhi(zh, mu) << 1;
+    u64 r = z.lo - qhat * m.q;
+    r = r >= 4 * m.q ? r - 4 * m.q : r;
+    r = r >= 2 * m.q ? r - 2 * m.q : r;
+    r = r >= m.q ? r - m.q : r;
+    return r;
+}
 PH_HD u64 mulmod(u64 a, u64 b, const Mod &m)
 {
     U128 z = mul128(a, b);
