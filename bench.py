@@ -259,22 +259,57 @@ def time_runs(op, steps, warmup, sync):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-def projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, steps, warmup, t_full_ms):
+def make_query_slots(torch, pie, cc, op, shape, depth, device, local_rank, gen, run_streams):
+    """depth - 1 further query slots on op's database: (context, operator, stream, idx, minus) each with its own synthetic
+    query resident in HBM (piehip_attach_database: the key and the packed database are shared by reference)"""
+    N, L, t, K, E = shape
+    slots = []
+    for _ in range(1, depth):
+        st = torch.cuda.Stream(device)
+        c = pie.PieContext(N, L, t, device=local_rank, stream=st.cuda_stream)
+        idx = uniform_limbs(torch, (K, E, 2), cc.q, N, device, gen)
+        minus = uniform_limbs(torch, (2,), cc.q, N, device, gen)
+        torch.cuda.synchronize(device)
+        o = pie.BatchedFHEHIPPIE(c, attachTo=op)
+        o.setIndexDevice(idx.data_ptr())
+        o.setMinusCompareElementDevice(minus.data_ptr())
+        c.set_run_streams(run_streams)
+        slots.append((c, o, st, idx, minus))
+    return slots
+
+
+def time_slots(ops, steps, warmup, sync):
+    """ms per run() with the operators taking the steps round-robin (len(ops) queries in flight)"""
+    for i in range(warmup):
+        ops[i % len(ops)].run(sync=False)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ops[i % len(ops)].run(sync=False)
+    sync()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+PROJECTION_IN_FLIGHT = 6
+
+
+def projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, steps, warmup):
     """SURVEY 8e without an 8-GPU box: a rank of G owns ceil(b / G) bin layers (the slowest rank sets the time), so
     speed-up(G) = t(b) / t(ceil(b / G)), every t measured here on one GPU with the same kernels, queues and launch path.
     Leaves out the result gather (b * 2LW bytes in total, each slice over its own xGMI link) and the broadcast of the query."""
     out = {"note": "t(n) = ms per run() over n bin layers on this one GPU; speedup(G) = t(b) / t(ceil(b/G)); excludes the RCCL "
-                   "gather of b*2LW result bytes and the query broadcast; cap = b / ceil(b/G)", "rows": {}}
+                   "gather of b*2LW result bytes and the query broadcast; cap = b / ceil(b/G).  Two tables: one query at a time "
+                   "(latency: the better of eager launches and a replayed hipGraph), and %d queries in flight on query slots "
+                   "(throughput: a rank's small share leaves most of the chip idle, further queries fill it)" % PROJECTION_IN_FLIGHT,
+           "queries_in_flight": PROJECTION_IN_FLIGHT, "rows": {}}
     N, L, t = cfg["N"], cfg["L"], cfg["t"]
+    sync = lambda: torch.cuda.synchronize(device)
     for name, row in SCALING_ROWS.items():
         c2 = dict(cfg, **row)
         b = c2["b"]
         shares = sorted({-(-b // G) for G in (1, 2, 4, 8)}, reverse=True)
-        tms, graph_better = {}, {}
+        tms, tfl, graph_better = {}, {}, {}
         for n in shares:
-            if name.startswith("C3") and n == b and t_full_ms is not None:
-                tms[n] = t_full_ms
-                continue
             stream = torch.cuda.Stream(device)
             cc = pie.PieContext(N, L, t, device=local_rank, stream=stream.cuda_stream)
             evk = uniform_limbs(torch, (L, 2), cc.q, N, device, gen)
@@ -282,16 +317,24 @@ def projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, steps, wa
             minus = uniform_limbs(torch, (2,), cc.q, N, device, gen)
             cc.load_relin_key(evk.cpu().numpy().view(np.uint64))
             op = synthetic_operator(pie, cc, c2, n, np.random.default_rng(n), (idx, minus))
-            te = time_runs(op, steps, warmup, lambda: torch.cuda.synchronize(device))
+            te = time_runs(op, steps, warmup, sync)
             cc.set_graph(True)     # a rank evaluating few bin layers is bound by the launch path: take the better of the two
-            tg = time_runs(op, steps, warmup, lambda: torch.cuda.synchronize(device))
+            tg = time_runs(op, steps, warmup, sync)
+            cc.set_graph(False)
             tms[n] = min(te, tg)
             graph_better[n] = tg < te
+            cc.set_run_streams(1)
+            more = make_query_slots(torch, pie, cc, op, (N, L, t, c2["K"], c2["E"]), PROJECTION_IN_FLIGHT, device, local_rank, gen, 1)
+            tfl[n] = time_slots([op] + [m[1] for m in more], max(600, steps * 4), max(120, warmup * 4), sync)
+            for m in reversed(more):
+                m[0].close()
             cc.close()
-            del op, cc, idx, minus, evk
+            del op, cc, idx, minus, evk, more
         out["rows"][name] = {"b": b, "E": c2["E"], "ms_per_run": {str(n): tms[n] for n in shares},
                              "hipgraph_faster": {str(n): bool(v) for n, v in graph_better.items()},
                              "speedup": {str(G): tms[b] / tms[-(-b // G)] for G in (2, 4, 8)},
+                             "ms_per_run_in_flight": {str(n): tfl[n] for n in shares},
+                             "speedup_in_flight": {str(G): tfl[b] / tfl[-(-b // G)] for G in (2, 4, 8)},
                              "cap": {str(G): b / -(-b // G) for G in (2, 4, 8)}}
     return out
 
@@ -360,6 +403,9 @@ def main():
     ap.add_argument("--no-projection", action="store_true", help="skip the projected strong-scaling legs")
     ap.add_argument("--no-ref-timer", action="store_true", help="skip the host-inputs (reference timer placement) leg")
     ap.add_argument("--graph", action="store_true", help="run() as one captured hipGraph (piehip_set_graph)")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="queries in flight: query slots (own stream + workspace, one shared database: piehip_attach_database) that "
+                         "run() round-robin.  0 = default (2; 6 for a rank's share of fewer than 8 bin layers), 1 = one query at a time")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams run() spreads the bin layers over (0 = library default, 1 = serial: every kernel alone on the GPU)")
     ap.add_argument("--collective", default="auto", choices=["auto", "gather", "all_gather"],
@@ -423,10 +469,25 @@ def main():
     torch.cuda.synchronize(device)
     cc.load_relin_key(evk.cpu().numpy().view(np.uint64))
     op = synthetic_operator(pie, cc, cfg, b_local, rng, (idx, minus)) if b_local > 0 else None
-    cc.set_run_streams(args.streams)
+    # Queries in flight.  One query's ct x pt stage is HBM-bound while another's transforms are ALU-bound, and a small share
+    # of bin layers leaves most of the chip idle: further query slots (a context with its own stream and run() workspace,
+    # reading slot 0's key and database by reference) take the steps round-robin.  Every step is still one full run() over
+    # its own inputs into its own result buffer.  With slots, one queue per run() is the faster setting (measured).
+    share = -(-b_total // world) if (scaling == "strong" and world > 1) else b_local   # the same on every rank
+    in_flight = args.in_flight or (2 if share >= 8 else 6)
+    if args.graph:
+        in_flight = 1
+    run_streams = args.streams or (1 if in_flight > 1 else 0)
+    cc.set_run_streams(run_streams)
     cc.set_graph(args.graph)
+    slots = [(cc, op, stream, idx, minus)]
+    if in_flight > 1 and op is not None:
+        slots += make_query_slots(torch, pie, cc, op, (N, L, t, K, E), in_flight, device, local_rank, gen, run_streams)
+    elif in_flight > 1:   # a rank without bin layers still takes part in every slot's collective
+        slots += [(None, None, torch.cuda.Stream(device), None, None) for _ in range(1, in_flight)]
     ct_words = 2 * L * N
     rg = None
+    rgs = []
     if use_dist:
         if args.collective == "auto":
             # both move the same payload; which one RCCL runs faster over this node's xGMI topology is measured, not assumed
@@ -455,17 +516,22 @@ def main():
                 args.collective = "all_gather"
             if rank == 0:
                 sys.stderr.write("collective timing (5 rounds, s): %s -> %s\n" % (times, args.collective))
-        rg = shard.ResultGather(op, b_total, b_local, ct_words, device, stream, kind=args.collective)
+        # one double-buffered gather per query slot (slots without bin layers still take part in the collective)
+        rgs = [shard.ResultGather(s_[1], b_total, b_local, ct_words, device, s_[2], kind=args.collective) for s_ in slots]
+        rg = rgs[0]
+    nstep = [0]
 
     def step():
-        if rg is not None:
-            rg.step()      # run() into a gather buffer, then the path's only collective, double-buffered
+        i_ = nstep[0] % len(slots)
+        nstep[0] += 1
+        if rgs:
+            rgs[i_].step()      # run() into a gather buffer, then the path's only collective, double-buffered
         elif op is not None:
-            op.run(sync=False)
+            slots[i_][1].run(sync=False)
 
     def drain():
-        if rg is not None:
-            rg.drain()
+        for r_ in rgs:
+            r_.drain()
 
     for _ in range(args.warmup):
         step()
@@ -505,7 +571,7 @@ def main():
                 for key in a:
                     a[key] += rec[key]
         cc.set_profiling(False)
-        cc.set_run_streams(args.streams)
+        cc.set_run_streams(run_streams)
         for name, a in agg.items():
             kernels[name] = dict(launches_per_step=a["launches"] / args.profile_steps, us_per_step=1e3 * a["ms"] / args.profile_steps,
                                  alg_GBps=a["alg_bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else None)
@@ -519,7 +585,7 @@ def main():
                         "avg_launch_us": 1e3 * ntt_ms / ntt_launch, "alg_bytes_per_launch": ntt_bytes / ntt_launch,
                         "launches_per_step": ntt_launch / args.profile_steps,
                         "measured": "HIP events around every launch, %d serial passes of run() (one stream; the timed region uses %s)"
-                                    % (args.profile_steps, "the library default of 2 queues" if args.streams == 0 else "%d" % args.streams)}
+                                    % (args.profile_steps, "%d queue(s) per run(), %d queries in flight" % (run_streams or 2, in_flight))}
 
     if rank == 0:
         value = b_total / (ms_per_step * 1e-3)
@@ -533,9 +599,10 @@ def main():
                                    % (cname, N, L, t, cfg["S"].bit_length() - 1, cfg["C"].bit_length() - 1, cfg["k"], cfg["e"], B, K, E,
                                       b_total, b_local, b_total * K * E, b_total * (K - 1), b_total),
                        "result_ciphertexts_per_step": b_total, "parallelism": "bins%d" % world,
-                       "collective": ("rccl %s of results" % args.collective) if use_dist else "none"},
+                       "collective": ("rccl %s of results" % args.collective) if use_dist else "none",
+                       "queries_in_flight": in_flight},
             "mac_per_s": b_total * K * E / (ms_per_step * 1e-3), "mul_per_s": b_total * (K - 1) / (ms_per_step * 1e-3),
-            "run_streams": args.streams if args.streams else 2, "hipgraph": bool(args.graph),
+            "queries_in_flight": in_flight, "run_streams": run_streams or 2, "hipgraph": bool(args.graph),
             # whole run(): algorithmic bytes of the REFERENCE's unfused schedule over the measured time.  Not HBM
             # utilisation: this build's schedule moves fewer bytes than the formula counts (fused stage A, 95 instead of 111
             # limb transforms per multiplication), so the fraction says how far the run is from the 8 TB/s bound of that schedule
@@ -545,6 +612,12 @@ def main():
                              "note": "bytes of the reference's unfused schedule / measured time / 8 TB/s; not measured HBM traffic"},
             "roofline": roofline, "kernels": kernels,
         }
+        if world == 1 and op is not None and in_flight > 1 and not args.bins_per_rank:
+            # the same steps with one query at a time (one slot, the library's default of two queues per run())
+            cc.set_run_streams(args.streams)
+            one_ms = time_runs(op, args.steps, args.warmup, lambda: torch.cuda.synchronize(device))
+            cc.set_run_streams(run_streams)
+            line["one_query_at_a_time"] = {"ms_per_step": one_ms, "value": b_total / (one_ms * 1e-3), "run_streams": args.streams or 2}
         if world == 1 and op is not None and not args.no_ref_timer:
             rt = reference_timer(torch, op, idx, minus, b_local, 15, device)
             line["ref_timer"] = rt
@@ -552,7 +625,7 @@ def main():
             line["value_ref_timer"] = rt["value_run_host_pinned_with_results"]
         if world == 1 and not args.no_projection and args.config == "C3" and not args.bins_per_rank:
             line["projected_strong_scaling"] = projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, max(20, args.steps // 4),
-                                                                        max(5, args.warmup // 2), ms_per_step if args.streams == 0 else None)
+                                                                        max(5, args.warmup // 2))
         if not args.no_e2e and world == 1:
             line["e2e_psi"] = e2e_psi(cfg, pie, cc, lambda: torch.cuda.synchronize(device))
         if not args.no_cpu_baseline and world == 1:
@@ -570,7 +643,9 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
-    cc.close()
+    for s_ in reversed(slots):
+        if s_[0] is not None:
+            s_[0].close()
 
 
 if __name__ == "__main__":

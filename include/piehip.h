@@ -154,6 +154,14 @@ int piehip_set_run_streams(piehip_handle h, uint32_t n);
  * count change.  Amortises the launch path when a handle evaluates few bin layers (one rank's share of a sharded server);
  * consecutive runs then do not overlap each other.  Off by default. */
 int piehip_set_graph(piehip_handle h, int on);
+/* A further query slot on the same database.  `h` (same device, same parameters) takes `owner`'s relinearisation key, packed
+ * database and masks by reference -- nothing is copied -- and gets a run() workspace of its own, so that queries set and
+ * run on the two handles (each on its own stream) overlap: one query's plaintext-ciphertext stage is HBM-bound while the
+ * other's transforms are ALU-bound.  The reference operator evaluates one query at a time (BatchedFHEHIPPIE.cpp:88-129);
+ * this is how a server with several clients keeps the GPU full.  `owner` must outlive `h` and must not reload its key or
+ * database while `h` is in use; loading a key or database into `h` itself returns it to a private copy (load_relin_key is
+ * refused while attached). */
+int piehip_attach_database(piehip_handle h, piehip_handle owner);
 /* getResultList (BatchedFHEHIPPIE.hpp:35-38): out[b][2][L][N] */
 int piehip_get_results(piehip_handle h, uint64_t *out);
 /* device address of the result buffer [b][2][L][N] (valid until destroy); for the RCCL gather */

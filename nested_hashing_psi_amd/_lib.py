@@ -47,6 +47,7 @@ SYMBOLS = {
     "piehip_host_buffers": (C.c_int, [C.c_void_p, C.POINTER(u64p), C.POINTER(u64p), C.POINTER(u64p)]),
     "piehip_set_run_streams": (C.c_int, [C.c_void_p, C.c_uint32]),
     "piehip_set_graph": (C.c_int, [C.c_void_p, C.c_int]),
+    "piehip_attach_database": (C.c_int, [C.c_void_p, C.c_void_p]),
     "piehip_get_results": (C.c_int, [C.c_void_p, u64p]),
     "piehip_results_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "piehip_copy_results_device": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -223,6 +223,9 @@ void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, cons
 //   sum_i y_i * hat[i] - v * prodmod
 // sum_i y[i] * c[i * stride] as a 128-bit integer.  MAD: carry-free column accumulators on v_mad_u64_u32
 // (madasm.h; needs all operands < 2^60 and NS <= 8), otherwise 64x64->128 multiplies.
+// Between the unrolled per-limb iterations of the base conversions: without it the scheduler hoists every iteration's
+// constants (scalar loads) to the top of the kernel, 200+ scalar registers' worth, and spills them into vector lanes.
+#define PIE_ITER_FENCE() __builtin_amdgcn_sched_barrier(0)
 template <u32 NS, bool MAD>
 __device__ __forceinline__ U128 dot128(const u64 *y, const u64 *c, u32 stride)
 {
@@ -288,7 +291,10 @@ __device__ __forceinline__ void expand_core(const DevConsts *dc, const u64 *x, u
     }
     const u64 v = (fsum + FIX_HALF) >> 60;
 #pragma unroll
-    for (u32 j = 0; j < Lp; j++) out[L + j] = crt_out<L, MAD>(y, &dc->qhat_modp[0][j], 8, v, dc->Q_modp[j], dc->mod[L + j]);
+    for (u32 j = 0; j < Lp; j++) {
+        PIE_ITER_FENCE();
+        out[L + j] = crt_out<L, MAD>(y, &dc->qhat_modp[0][j], 8, v, dc->Q_modp[j], dc->mod[L + j]);
+    }
 }
 
 // x[L] (mod Q) -> out[M]: P limbs = round(P x / Q), Q limbs = centred CRT lift of that
@@ -314,6 +320,7 @@ __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 *x,
     u64 fs2 = 0;
 #pragma unroll
     for (u32 j = 0; j < Lp; j++) {
+        PIE_ITER_FENCE();
         const Mod &pj = dc->mod[L + j];
         U128 acc = dot128<L, MAD>(y, &dc->PI_modp[0][j], 8);
         add128(acc, itot);
@@ -324,7 +331,10 @@ __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 *x,
     }
     const u64 v = (fs2 + FIX_HALF) >> 60;
 #pragma unroll
-    for (u32 i = 0; i < L; i++) out[i] = crt_out<Lp, MAD>(yp, &dc->phat_modq[0][i], 8, v, dc->P_modq[i], dc->mod[i]);
+    for (u32 i = 0; i < L; i++) {
+        PIE_ITER_FENCE();
+        out[i] = crt_out<Lp, MAD>(yp, &dc->phat_modq[0][i], 8, v, dc->P_modq[i], dc->mod[i]);
+    }
 }
 
 // SKIPQ (centred lift only): leave the Q limbs of the output alone, they already hold the operand's EVALUATION form
@@ -461,6 +471,7 @@ __device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 
     add128(itot, U128{(fsum + FIX_HALF) >> 60, 0});
 #pragma unroll
     for (u32 k = 0; k < L; k++) {
+        PIE_ITER_FENCE();
         const Mod &qk = dc->mod[k];
         U128 acc = dot128<Lp, MAD>(yp, &dc->tQF_modq[0][k], 8);
         mac128(acc, d[k], dc->tPinv_modq[k]);

@@ -114,6 +114,7 @@ struct piehip_ctx {
     u32 hk = 0, he = 0, hb = 0;  // table dimensions ([k][e][K][hb][E]; hb = all bin layers, of which this handle keeps b)
     NttPlan plan;
     // keys / database / inputs
+    bool db_borrowed = false;  // piehip_attach_database: d_evk*, d_db, d_masks* belong to another handle (never freed or written here)
     u64 *d_evk = nullptr;
     u32 K = 0, b = 0, E = 0;
     u64 *d_db = nullptr, *d_masks = nullptr;
@@ -549,12 +550,21 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
     return PIEHIP_OK;
 }
 
+// a handle that borrowed its database and key (piehip_attach_database) lets go of them: pointers only
+static void detach_database(piehip_ctx *h)
+{
+    if (!h->db_borrowed) return;
+    h->d_evk = h->d_evk_sigma = h->d_db = h->d_masks = h->d_masks_sigma = nullptr;
+    h->db_borrowed = false;
+}
+
 int piehip_destroy(piehip_handle h)
 {
     if (!h) return PIEHIP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->pool) (void)hipEventDestroy(e);
+    detach_database(h);
     dev_free(&h->d_evk);
     dev_free(&h->d_db);
     dev_free(&h->d_masks);
@@ -638,6 +648,7 @@ int piehip_load_relin_key(piehip_handle h, const uint64_t *evk)
 {
     NEED(h);
     if (!evk) return fail(PIEHIP_EINVAL, "null evk");
+    if (h->db_borrowed) return fail(PIEHIP_EINVAL, "this handle uses another handle's key and database (piehip_attach_database)");
     HIPCHK(hipSetDevice(h->device));
     const size_t words = (size_t)h->hp.L * 2 * h->LN();
     if (!h->d_evk) {
@@ -672,13 +683,17 @@ static int make_masks_sigma(piehip_ctx *h)
     return PIEHIP_OK;
 }
 
-static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E)
+static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E, bool with_db = true)
 {
     drop_graph(h);  // the captured launches hold the addresses and shapes of the buffers below
+    if (h->db_borrowed && with_db) {  // a database of its own from here on; the key goes back too (load it again)
+        detach_database(h);
+        h->K = h->b = h->E = 0;
+    }
     if (K < 2) return fail(PIEHIP_EINVAL, "Cuckoo Table needs more than one hash function!");  // CuckooHashTable.cpp:39-42
     if (b < 1 || E < 1) return fail(PIEHIP_EINVAL, "Bin size needs to be at least of size one!");
     const size_t LN = h->LN();
-    if (h->K == K && h->b == b && h->E == E && h->d_db && h->d_masks && h->d_acc && h->d_out && h->ws.nb == b) {
+    if (with_db && h->K == K && h->b == b && h->E == E && h->d_db && h->d_masks && h->d_acc && h->d_out && h->ws.nb == b) {
         // same shape as the database being replaced (or reserved): keep the 0.5 GiB of buffers (hipFree + hipMalloc cost
         // ~10 ms); the inputs of the previous database are stale
         h->d_idx = nullptr;
@@ -693,8 +708,8 @@ static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E)
     ws_free(h->ws);
     h->K = h->b = h->E = 0;
     int rc;
-    if ((rc = dev_alloc(&h->d_db, (size_t)K * b * E * LN))) return rc;
-    if ((rc = dev_alloc(&h->d_masks, (size_t)b * LN))) return rc;
+    if (with_db && (rc = dev_alloc(&h->d_db, (size_t)K * b * E * LN))) return rc;
+    if (with_db && (rc = dev_alloc(&h->d_masks, (size_t)b * LN))) return rc;
     if ((rc = dev_alloc(&h->d_acc, (size_t)b * K * 2 * LN))) return rc;
     if ((rc = dev_alloc(&h->d_out, (size_t)b * 2 * LN))) return rc;
     if (K > 2 && (rc = dev_alloc(&h->d_prod, (size_t)b * 2 * LN))) return rc;
@@ -720,6 +735,43 @@ int piehip_load_db(piehip_handle h, uint32_t K, uint32_t b, uint32_t E, const ui
     HIPCHK(hipMemcpyAsync(h->d_masks, masks, sizeof(u64) * (size_t)b * LN, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return make_masks_sigma(h);
+}
+
+// Another query slot on the same database: `h` takes `owner`'s relinearisation key, database and masks by reference (device
+// pointers; nothing is copied) and gets a run() workspace of its own, so that run() calls on the two handles -- each on its
+// own stream -- overlap.  One query's stage A is HBM-bound while another's transforms are ALU-bound: two handles with one
+// queue each finish two queries 10 % sooner than one handle with two queues finishes them one after the other (DESIGN.md
+// section 6).  The owner must outlive the borrower and must not reload its key or database while the borrower is in use.
+int piehip_attach_database(piehip_handle h, piehip_handle owner)
+{
+    NEED(h);
+    if (!owner || owner == h) return fail(PIEHIP_EINVAL, "attach_database: needs another handle");
+    join_pending(owner);
+    if (owner->db_borrowed) return fail(PIEHIP_EINVAL, "attach_database: the owner itself borrows its database");
+    if (!owner->d_db || !owner->d_evk) return fail(PIEHIP_ESTATE, "attach_database: the owner has no key or no database yet");
+    if (owner->device != h->device) return fail(PIEHIP_EINVAL, "attach_database: handles on different devices");
+    if (owner->hp.N != h->hp.N || owner->hp.L != h->hp.L || owner->hp.t != h->hp.t || owner->hp.moduli != h->hp.moduli)
+        return fail(PIEHIP_EINVAL, "attach_database: handles with different parameters");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(owner->stream));  // uploads of the owner's key / database have landed
+    if (!h->db_borrowed) {
+        dev_free(&h->d_evk);
+        dev_free(&h->d_evk_sigma);
+        dev_free(&h->d_db);
+        dev_free(&h->d_masks);
+        dev_free(&h->d_masks_sigma);
+    }
+    detach_database(h);
+    h->K = h->b = h->E = 0;
+    int rc = alloc_run_buffers(h, owner->K, owner->b, owner->E, false);
+    if (rc) return rc;
+    h->d_evk = owner->d_evk;
+    h->d_evk_sigma = owner->d_evk_sigma;
+    h->d_db = owner->d_db;
+    h->d_masks = owner->d_masks;
+    h->d_masks_sigma = owner->d_masks_sigma;
+    h->db_borrowed = true;
+    return PIEHIP_OK;
 }
 
 static const u32 ENCODE_CHUNK = 256;  // plaintexts per batch of the device encoder (bounds its mod-t scratch)

@@ -213,7 +213,7 @@ class BatchedFHEHIPPIE:
 
     def __init__(self, cryptoContext, vectorizedHCT=None, preCalcRandomMask=None, slots=None, mask_slots=None,
                  serverStashSize=0, simpleMultiTables=True, cuckooMultiTables=True, serverSet=None, hashParams=None,
-                 hashTable=None, shuffle_seed=None, mask_seed=None, binSlice=None):
+                 hashTable=None, shuffle_seed=None, mask_seed=None, binSlice=None, attachTo=None):
         # Seeds of the Cuckoo evictions, the bin-layer shuffle and the random masks: secret by default (OS CSPRNG), as the
         # reference draws them from std::random_device (BatchedFHEHIPPIE.cpp:25-26,72-82; CuckooHashTable.cpp:51-52).
         # The masks hide prod_h(item - x) of non-matching slots from the client.  Explicit seeds are for parity tests.
@@ -229,7 +229,12 @@ class BatchedFHEHIPPIE:
         # database must be given the same seeds
         if binSlice is not None and serverSet is None and hashTable is None:
             raise ValueError("binSlice applies to databases built from a server set or a hash table")
-        if serverSet is not None:
+        if attachTo is not None:
+            # a further query slot on attachTo's database and key (piehip_attach_database): own context, stream and workspace
+            self.K, self.b, self.E = attachTo.K, attachTo.b, attachTo.E
+            _check(lib().piehip_attach_database(h, attachTo.cc._h))
+            self._owner = attachTo  # keeps the database alive
+        elif serverSet is not None:
             # the whole offline phase on the device: nested hashing (HierarchicalCuckooHashTable::insertAll) +
             # the reference constructor's shuffle / gather / encode.  hashParams: k, e, K, b, E, hash_seed,
             # evict_seed, shuffle_seed, mask_seed
@@ -350,6 +355,41 @@ class BatchedFHEHIPPIE:
         p = C.c_void_p()
         _check(lib().piehip_results_device(self.cc._h, C.byref(p)))
         return p.value
+
+
+class QueryPipeline:
+    """Several queries in flight on one database: `depth` query slots, each a context with its own stream and run() workspace,
+    all reading slot 0's key and packed database (piehip_attach_database).  submit() hands the next query to the next slot
+    and returns it; slot.run(sync=False) calls of different slots overlap on the GPU.  Serving-side addition: the reference
+    operator evaluates one query at a time."""
+
+    def __init__(self, op, depth, make_context):
+        """op: the operator that owns the database; make_context(): a fresh PieContext with the same parameters on its own
+        stream (called depth - 1 times)"""
+        self.slots = [op] + [BatchedFHEHIPPIE(make_context(), attachTo=op) for _ in range(depth - 1)]
+        self._next = 0
+
+    def submit(self, d_idx, d_minus, d_results=None):
+        """enqueue one query whose inputs live in HBM (device addresses); returns the slot that evaluates it"""
+        s = self.slots[self._next]
+        self._next = (self._next + 1) % len(self.slots)
+        s.setIndexDevice(d_idx)
+        s.setMinusCompareElementDevice(d_minus)
+        s.run(sync=False, into=d_results)
+        return s
+
+    def run_all(self):
+        """one more run() on every slot with the inputs it already has (benchmarks)"""
+        for s in self.slots:
+            s.run(sync=False)
+
+    def sync(self):
+        for s in self.slots:
+            s.sync()
+
+    def close(self):
+        for s in self.slots[1:]:
+            s.cc.close()
 
 
 class FHEHIPPIE:

@@ -536,6 +536,52 @@ def test_run_as_captured_graph(ob, pie, streams):
     cc.close()
 
 
+@pytest.mark.parametrize("N,L,K,E,b,depth", [(4096, 2, 2, 4, 5, 2), (16384, 4, 2, 3, 9, 3)])
+def test_query_slots_on_one_database(ob, pie, N, L, K, E, b, depth):
+    """piehip_attach_database: further query slots (own context, stream, workspace) read the owner's key and database by
+    reference; different queries run on the slots at the same time and each gets the oracle's result; a slot that is closed
+    leaves the owner intact; loading a key into an attached slot is refused; a slot given its own database detaches"""
+    import torch
+    t = T16 if N == 4096 else T32
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(N + depth)
+    db, masks, evk = rand_limbs(rng, cc.q, (K, b, E), N), rand_limbs(rng, cc.q, (b,), N), rand_limbs(rng, cc.q, (L, 2), N)
+    cc.load_relin_key(evk)
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    streams = [torch.cuda.Stream() for _ in range(depth - 1)]
+    it = iter(streams)
+    pipe = pie.QueryPipeline(op, depth, lambda: pie.PieContext(N, L, t, stream=next(it).cuda_stream))
+    for rnd in range(2):
+        queries = [(rand_limbs(rng, cc.q, (K, E, 2), N), rand_limbs(rng, cc.q, (2,), N)) for _ in range(depth)]
+        for s, (idx, minus) in zip(pipe.slots, queries):
+            s.setMinusCompareElement(minus)
+            s.setIndex(idx)
+        for _ in range(3):  # several rounds in flight, all slots at once
+            pipe.run_all()
+        pipe.sync()
+        for s, (idx, minus) in zip(pipe.slots, queries):
+            assert (s.getResultList() == o.pie_run(idx, minus, db, masks, evk)).all()
+    with pytest.raises(ValueError):
+        pipe.slots[1].cc.load_relin_key(evk)
+    # a slot with a database of its own: detached, the owner's buffers untouched
+    db2, masks2 = rand_limbs(rng, cc.q, (K, 3, E), N), rand_limbs(rng, cc.q, (3,), N)
+    c1 = pipe.slots[1].cc
+    op2 = pie.BatchedFHEHIPPIE(c1, vectorizedHCT=db2, preCalcRandomMask=masks2)
+    c1.load_relin_key(evk)
+    idx, minus = queries[0]
+    op2.setMinusCompareElement(minus)
+    op2.setIndex(idx)
+    op2.run()
+    assert (op2.getResultList() == o.pie_run(idx, minus, db2, masks2, evk)).all()
+    pipe.close()
+    op.setMinusCompareElement(minus)
+    op.setIndex(idx)
+    op.run()
+    assert (op.getResultList() == o.pie_run(idx, minus, db, masks, evk)).all()
+    cc.close()
+
+
 @pytest.mark.parametrize("N,L,K,E,b", [(4096, 2, 2, 5, 5), (16384, 4, 2, 3, 4), (8192, 3, 3, 4, 3)])
 def test_run_host_pipelined_call_matches_separate_calls(ob, pie, N, L, K, E, b):
     """piehip_run_host (row-wise upload under stage A, per-group download) == setMinusCompareElement + setIndex + run +
