@@ -219,32 +219,51 @@ void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, cons
 // stride N and writes every output limb.  Rounding terms use the 60-bit fixed-point rule of
 // modarith.h (identical to oracle/pie_oracle.c: po_expand_q_to_qp, po_scale_pq_expand, po_scale_round_tp).
 // ---------------------------------------------------------------------------------------------
-// centred CRT lift of y_i-weighted residues from a source basis into target modulus `tm`:
-//   sum_i y_i * hat[i] - v * prodmod
-// sum_i y[i] * c[i * stride] as a 128-bit integer.  MAD: carry-free column accumulators on v_mad_u64_u32
-// (madasm.h; needs all operands < 2^60 and NS <= 8), otherwise 64x64->128 multiplies.
-// Between the unrolled per-limb iterations of the base conversions: without it the scheduler hoists every iteration's
-// constants (scalar loads) to the top of the kernel, 200+ scalar registers' worth, and spills them into vector lanes.
+// The per-limb iterations of the base conversions are unrolled (the residue arrays must stay in registers), and each
+// iteration needs its own dozen table entries: moduli, Barrett and Shoup constants, one column of a conversion matrix.
+// Left alone, the compiler loads all of them at the top of the kernel -- 200+ scalar registers' worth -- and spills them
+// into vector lanes (a third of the instructions of these kernels were v_readlane / v_writelane / v_mov).  So every
+// iteration starts with a scheduling fence and reads its constants through a freshly laundered pointer into the
+// constant address space: scalar loads, issued in that iteration, dead at its end.
 #define PIE_ITER_FENCE() __builtin_amdgcn_sched_barrier(0)
+typedef const __attribute__((address_space(4))) DevConsts *DcC;
+__device__ __forceinline__ DcC dc_iter(const DevConsts *dc)
+{
+    u64 v = (u64)dc;
+    asm volatile("" : "+s"(v));
+    return (DcC)v;
+}
+__device__ __forceinline__ Mod ld_mod(DcC c, u32 i)
+{
+    Mod m;
+    m.q = c->mod[i].q, m.r0 = c->mod[i].r0, m.r1 = c->mod[i].r1, m.n_inv = 0, m.n_inv_sh = 0;
+    m.fconst = c->mod[i].fconst, m.fshift = c->mod[i].fshift, m.pad = 0;
+    return m;
+}
+
+// sum_i y[i] * c[i] as a 128-bit integer.  MAD: carry-free column accumulators on v_mad_u64_u32 (madasm.h; needs all
+// operands < 2^60 and NS <= 8), otherwise 64x64->128 multiplies.
 template <u32 NS, bool MAD>
-__device__ __forceinline__ U128 dot128(const u64 *y, const u64 *c, u32 stride)
+__device__ __forceinline__ U128 dot128(const u64 *y, const u64 (&c)[NS])
 {
     if (MAD) {
         ColAcc a = {0, 0, 0};
 #pragma unroll
-        for (u32 i = 0; i < NS; i++) colacc_mac(a, split30(y[i]), split30(c[(size_t)i * stride]));
+        for (u32 i = 0; i < NS; i++) colacc_mac(a, split30(y[i]), split30(c[i]));
         return colacc_value(a);
     }
     U128 acc = {0, 0};
 #pragma unroll
-    for (u32 i = 0; i < NS; i++) mac128(acc, y[i], c[(size_t)i * stride]);
+    for (u32 i = 0; i < NS; i++) mac128(acc, y[i], c[i]);
     return acc;
 }
 
+// centred CRT lift of y_i-weighted residues from a source basis into target modulus `tm`:
+//   sum_i y_i * hat[i] - v * prodmod
 template <u32 NS, bool MAD>
-__device__ __forceinline__ u64 crt_out(const u64 *y, const u64 *hat, u32 hat_stride, u64 v, u64 prodmod, const Mod &tm)
+__device__ __forceinline__ u64 crt_out(const u64 *y, const u64 (&hat)[NS], u64 v, u64 prodmod, const Mod &tm)
 {
-    U128 acc = dot128<NS, MAD>(y, hat, hat_stride);
+    U128 acc = dot128<NS, MAD>(y, hat);
     mac128(acc, v, tm.q - prodmod);  // - v * prodmod (mod tm); v <= ns: one Barrett reduction for the whole sum
     // MAD implies 2^59 < q < 2^60 for every modulus: up to 7 products plus the small terms stay below 2^123
     return (MAD && NS <= 7) ? reduce123(acc, tm) : reduce128(acc, tm);
@@ -259,81 +278,126 @@ __device__ __forceinline__ u64 crt_out(const u64 *y, const u64 *hat, u32 hat_str
 // below 8q, so neither side reduces sums or differences: the Shoup product accepts any 64-bit operand.
 __device__ __forceinline__ void fold_load(const DevConsts *dc, u32 a, u64 u, u64 v, u64 &x0, u64 &x1)
 {
-    const u64 q = dc->mod[a].q;
-    x0 = mul_shoup(u + v, dc->fold_ia[a], dc->fold_ia_sh[a], q);
-    x1 = mul_shoup(u + (4 * q - v), dc->fold_ib[a], dc->fold_ib_sh[a], q);
+    PIE_ITER_FENCE();
+    const DcC c = dc_iter(dc);
+    const u64 q = c->mod[a].q;
+    x0 = mul_shoup(u + v, c->fold_ia[a], c->fold_ia_sh[a], q);
+    x1 = mul_shoup(u + (4 * q - v), c->fold_ib[a], c->fold_ib_sh[a], q);
 }
 // u canonical; results in (0, 3q)
 __device__ __forceinline__ void fold_store(const DevConsts *dc, u32 a, u64 u, u64 v, u64 &y0, u64 &y1)
 {
-    const u64 q = dc->mod[a].q;
-    const u64 t = mul_shoup_lazy(v, dc->fold_w[a], dc->fold_w_sh[a], q);  // [0, 2q)
+    const DcC c = dc_iter(dc);
+    const u64 q = c->mod[a].q;
+    const u64 t = mul_shoup_lazy(v, c->fold_w[a], c->fold_w_sh[a], q);  // [0, 2q)
     y0 = u + t;
     y1 = u + (2 * q - t);
 }
 
 // The RNS width L is a template parameter: with run-time trip counts hipcc indexes the per-coefficient residue
-// arrays dynamically and spills them to scratch.
+// arrays dynamically and spills them to scratch.  NP coefficients (1, or the 2 of a folded pair) go through every
+// iteration together and share its constants.
 // x[L] (mod Q) -> out[M]: Q limbs copied, P limbs = centred CRT lift
 // YIN: x[] already holds the CRT digits y_i = [x_i (Q/q_i)^-1]_{q_i} (folded load with the merged constants); the Q
 // limbs of the output are then not produced
-template <u32 L, bool MAD, bool YIN = false>
-__device__ __forceinline__ void expand_core(const DevConsts *dc, const u64 *x, u64 *out)
+template <u32 L, bool MAD, bool YIN, int NP>
+__device__ __forceinline__ void expand_core(const DevConsts *dc, const u64 (&x)[NP][L], u64 (&out)[NP][2 * L + 1])
 {
     constexpr u32 Lp = L + 1;
-    u64 y[L];
-    u64 fsum = 0;
+    u64 y[NP][L];
+    u64 fsum[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) fsum[p] = 0;
 #pragma unroll
     for (u32 i = 0; i < L; i++) {
-        out[i] = x[i];
-        y[i] = YIN ? x[i] : mul_shoup(x[i], dc->qhat_inv[i], dc->qhat_inv_sh[i], dc->mod[i].q);
-        fsum += fixfrac(y[i], dc->mod[i]);
+        PIE_ITER_FENCE();
+        const DcC c = dc_iter(dc);
+        const Mod mi = ld_mod(c, i);
+        const u64 w = c->qhat_inv[i], wsh = c->qhat_inv_sh[i];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            out[p][i] = x[p][i];
+            y[p][i] = YIN ? x[p][i] : mul_shoup(x[p][i], w, wsh, mi.q);
+            fsum[p] += fixfrac(y[p][i], mi);
+        }
     }
-    const u64 v = (fsum + FIX_HALF) >> 60;
 #pragma unroll
     for (u32 j = 0; j < Lp; j++) {
         PIE_ITER_FENCE();
-        out[L + j] = crt_out<L, MAD>(y, &dc->qhat_modp[0][j], 8, v, dc->Q_modp[j], dc->mod[L + j]);
+        const DcC c = dc_iter(dc);
+        const Mod pj = ld_mod(c, L + j);
+        u64 hat[L];
+#pragma unroll
+        for (u32 i = 0; i < L; i++) hat[i] = c->qhat_modp[i][j];
+        const u64 prodmod = c->Q_modp[j];
+#pragma unroll
+        for (int p = 0; p < NP; p++) out[p][L + j] = crt_out<L, MAD>(y[p], hat, (fsum[p] + FIX_HALF) >> 60, prodmod, pj);
     }
 }
 
 // x[L] (mod Q) -> out[M]: P limbs = round(P x / Q), Q limbs = centred CRT lift of that
-template <u32 L, bool MAD, bool YIN = false>
-__device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 *x, u64 *out)
+template <u32 L, bool MAD, bool YIN, int NP>
+__device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 (&x)[NP][L], u64 (&out)[NP][2 * L + 1])
 {
     constexpr u32 Lp = L + 1;
-    u64 y[L];
-    u64 fsum = 0;
-    U128 itot = {0, 0};
+    u64 y[NP][L];
+    u64 fsum[NP];
+    U128 itot[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) fsum[p] = 0, itot[p] = U128{0, 0};
 #pragma unroll
     for (u32 i = 0; i < L; i++) {
-        const Mod &mi = dc->mod[i];
-        y[i] = YIN ? x[i] : mul_shoup(x[i], dc->qhat_inv[i], dc->qhat_inv_sh[i], mi.q);
-        // y_i P / q_i = y_i floor(P/q_i) + floor(y_i w_i / q_i) + (y_i w_i mod q_i) / q_i
-        u64 fl, z;
-        divmod_shoup(y[i], dc->P_modq[i], dc->P_modq_sh[i], mi.q, fl, z);
-        add128(itot, U128{fl, 0});
-        fsum += fixfrac(z, mi);
+        PIE_ITER_FENCE();
+        const DcC c = dc_iter(dc);
+        const Mod mi = ld_mod(c, i);
+        const u64 w = c->qhat_inv[i], wsh = c->qhat_inv_sh[i], pw = c->P_modq[i], pwsh = c->P_modq_sh[i];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            y[p][i] = YIN ? x[p][i] : mul_shoup(x[p][i], w, wsh, mi.q);
+            // y_i P / q_i = y_i floor(P/q_i) + floor(y_i w_i / q_i) + (y_i w_i mod q_i) / q_i
+            u64 fl, z;
+            divmod_shoup(y[p][i], pw, pwsh, mi.q, fl, z);
+            add128(itot[p], U128{fl, 0});
+            fsum[p] += fixfrac(z, mi);
+        }
     }
-    add128(itot, U128{(fsum + FIX_HALF) >> 60, 0});
-    u64 yp[Lp];
-    u64 fs2 = 0;
+    u64 yp[NP][Lp];
+    u64 fs2[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        add128(itot[p], U128{(fsum[p] + FIX_HALF) >> 60, 0});
+        fs2[p] = 0;
+    }
 #pragma unroll
     for (u32 j = 0; j < Lp; j++) {
         PIE_ITER_FENCE();
-        const Mod &pj = dc->mod[L + j];
-        U128 acc = dot128<L, MAD>(y, &dc->PI_modp[0][j], 8);
-        add128(acc, itot);
-        const u64 r = MAD ? reduce123(acc, pj) : reduce128(acc, pj);  // L <= 7 products + a 64-bit term
-        out[L + j] = r;
-        yp[j] = mul_shoup(r, dc->phat_inv[j], dc->phat_inv_sh[j], pj.q);
-        fs2 += fixfrac(yp[j], pj);
+        const DcC c = dc_iter(dc);
+        const Mod pj = ld_mod(c, L + j);
+        u64 col[L];
+#pragma unroll
+        for (u32 i = 0; i < L; i++) col[i] = c->PI_modp[i][j];
+        const u64 w = c->phat_inv[j], wsh = c->phat_inv_sh[j];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            U128 acc = dot128<L, MAD>(y[p], col);
+            add128(acc, itot[p]);
+            const u64 r = MAD ? reduce123(acc, pj) : reduce128(acc, pj);  // L <= 7 products + a 64-bit term
+            out[p][L + j] = r;
+            yp[p][j] = mul_shoup(r, w, wsh, pj.q);
+            fs2[p] += fixfrac(yp[p][j], pj);
+        }
     }
-    const u64 v = (fs2 + FIX_HALF) >> 60;
 #pragma unroll
     for (u32 i = 0; i < L; i++) {
         PIE_ITER_FENCE();
-        out[i] = crt_out<Lp, MAD>(yp, &dc->phat_modq[0][i], 8, v, dc->P_modq[i], dc->mod[i]);
+        const DcC c = dc_iter(dc);
+        const Mod mi = ld_mod(c, i);
+        u64 hat[Lp];
+#pragma unroll
+        for (u32 j = 0; j < Lp; j++) hat[j] = c->phat_modq[j][i];
+        const u64 prodmod = c->P_modq[i];
+#pragma unroll
+        for (int p = 0; p < NP; p++) out[p][i] = crt_out<Lp, MAD>(yp[p], hat, (fs2[p] + FIX_HALF) >> 60, prodmod, mi);
     }
 }
 
@@ -356,25 +420,25 @@ __global__ void __launch_bounds__(TPB) expand_kernel(const DevConsts *__restrict
 #pragma unroll
     for (u32 i = 0; i < L; i++) {
         if (YIN) {
-            const u64 q = dc->mod[i].q, u = pin[(size_t)i * N], v = pin[(size_t)i * N + H];
-            x[0][i] = mul_shoup(u + v, dc->fold_iaq[i], dc->fold_iaq_sh[i], q);            // u, v in [0, 4q)
-            x[NP - 1][i] = mul_shoup(u + (4 * q - v), dc->fold_ibq[i], dc->fold_ibq_sh[i], q);
+            PIE_ITER_FENCE();
+            const DcC c = dc_iter(dc);
+            const u64 q = c->mod[i].q, u = pin[(size_t)i * N], v = pin[(size_t)i * N + H];
+            x[0][i] = mul_shoup(u + v, c->fold_iaq[i], c->fold_iaq_sh[i], q);            // u, v in [0, 4q)
+            x[NP - 1][i] = mul_shoup(u + (4 * q - v), c->fold_ibq[i], c->fold_ibq_sh[i], q);
         } else if (FOLD) {
             fold_load(dc, i, pin[(size_t)i * N], pin[(size_t)i * N + H], x[0][i], x[NP - 1][i]);
         } else {
             x[0][i] = pin[(size_t)i * N];
         }
     }
-#pragma unroll
-    for (int p = 0; p < NP; p++) {
-        if (SCALE)
-            scale_pq_core<L, MAD, YIN>(dc, x[p], y[p]);
-        else
-            expand_core<L, MAD, YIN>(dc, x[p], y[p]);
-    }
+    if (SCALE)
+        scale_pq_core<L, MAD, YIN, NP>(dc, x, y);
+    else
+        expand_core<L, MAD, YIN, NP>(dc, x, y);
 #pragma unroll
     for (u32 a = 0; a < M; a++) {
         if (!SCALE && a < L && SKIPQ) continue;  // (NttExtra)
+        PIE_ITER_FENCE();
         if (FOLD) {
             u64 y0, y1;
             fold_store(dc, a, y[0][a], y[NP - 1][a], y0, y1);
@@ -452,31 +516,48 @@ void launch_tensor(const DevConsts *dc, u32 N, u32 M, const u64 *e, u64 *d, u32 
 // Scale-and-round by t/P from QP into Q (row A6)
 // ---------------------------------------------------------------------------------------------
 // d[M] (mod QP) -> out[L]: round(t d / P) mod Q
-template <u32 L, bool MAD>
-__device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 *d, u64 *out)
+template <u32 L, bool MAD, int NP>
+__device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 (&d)[NP][2 * L + 1], u64 (&out)[NP][L])
 {
     constexpr u32 Lp = L + 1;
-    u64 yp[Lp];
-    u64 fsum = 0;
-    U128 itot = {0, 0};
+    u64 yp[NP][Lp];
+    u64 fsum[NP];
+    U128 itot[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) fsum[p] = 0, itot[p] = U128{0, 0};
 #pragma unroll
     for (u32 j = 0; j < Lp; j++) {
-        const Mod &pj = dc->mod[L + j];
-        yp[j] = mul_shoup(d[L + j], dc->qp_hat_inv[L + j], dc->qp_hat_inv_sh[L + j], pj.q);
-        u64 fl, z;
-        divmod_shoup(yp[j], dc->tQ_modp[j], dc->tQ_modp_sh[j], pj.q, fl, z);
-        add128(itot, U128{fl, 0});
-        fsum += fixfrac(z, pj);
+        PIE_ITER_FENCE();
+        const DcC c = dc_iter(dc);
+        const Mod pj = ld_mod(c, L + j);
+        const u64 w = c->qp_hat_inv[L + j], wsh = c->qp_hat_inv_sh[L + j], tw = c->tQ_modp[j], twsh = c->tQ_modp_sh[j];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            yp[p][j] = mul_shoup(d[p][L + j], w, wsh, pj.q);
+            u64 fl, z;
+            divmod_shoup(yp[p][j], tw, twsh, pj.q, fl, z);
+            add128(itot[p], U128{fl, 0});
+            fsum[p] += fixfrac(z, pj);
+        }
     }
-    add128(itot, U128{(fsum + FIX_HALF) >> 60, 0});
+#pragma unroll
+    for (int p = 0; p < NP; p++) add128(itot[p], U128{(fsum[p] + FIX_HALF) >> 60, 0});
 #pragma unroll
     for (u32 k = 0; k < L; k++) {
         PIE_ITER_FENCE();
-        const Mod &qk = dc->mod[k];
-        U128 acc = dot128<Lp, MAD>(yp, &dc->tQF_modq[0][k], 8);
-        mac128(acc, d[k], dc->tPinv_modq[k]);
-        add128(acc, itot);
-        out[k] = (MAD && L <= 5) ? reduce123(acc, qk) : reduce128(acc, qk);  // L + 2 products
+        const DcC c = dc_iter(dc);
+        const Mod qk = ld_mod(c, k);
+        u64 col[Lp];
+#pragma unroll
+        for (u32 j = 0; j < Lp; j++) col[j] = c->tQF_modq[j][k];
+        const u64 tp = c->tPinv_modq[k];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            U128 acc = dot128<Lp, MAD>(yp[p], col);
+            mac128(acc, d[p][k], tp);
+            add128(acc, itot[p]);
+            out[p][k] = (MAD && L <= 5) ? reduce123(acc, qk) : reduce128(acc, qk);  // L + 2 products
+        }
     }
 }
 
@@ -503,10 +584,10 @@ __global__ void __launch_bounds__(TPB) scale_round_kernel(const DevConsts *__res
         else
             x[0][a] = pin[(size_t)a * N];
     }
-#pragma unroll
-    for (int p = 0; p < NP; p++) scale_round_core<L, MAD>(dc, x[p], y[p]);
+    scale_round_core<L, MAD, NP>(dc, x, y);
 #pragma unroll
     for (u32 k = 0; k < L; k++) {
+        PIE_ITER_FENCE();
         if (FOLD) {
             u64 y0 = y[0][k], y1 = y[NP - 1][k];
             if (comp < 2 || fold_comp2) fold_store(dc, k, y[0][k], y[NP - 1][k], y0, y1);

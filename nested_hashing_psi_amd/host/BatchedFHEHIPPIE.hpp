@@ -120,9 +120,26 @@ public:
         resultList.resize(b);
     }
 
+    // A further query slot on `database`'s packed table and on its context's key (piehip_attach_database): `cryptoContext`
+    // is a second context with the same parameters, its own stream and run() workspace.  Queries set on the two operators
+    // evaluate at the same time (enqueue() on each, then collect() on each); the reference operator has no counterpart --
+    // it evaluates one query at a time -- and `database` must outlive the slot.
+    BatchedFHEHIPPIE(PieContext &cryptoContext, const BatchedFHEHIPPIE &database) : cc(cryptoContext)
+    {
+        K = database.K, b = database.b, E = database.E;
+        PieContext::check(piehip_attach_database(cc.handle(), database.cc.handle()));
+        resultList.resize(b);
+    }
+
     void run()  // BatchedFHEHIPPIE.cpp:88-129
     {
-        PieContext::check(piehip_run(cc.handle()));
+        enqueue();
+        collect();
+    }
+    // run() in two halves: the evaluation is asynchronous on the device; collect() waits for it and fills the result list
+    void enqueue() { PieContext::check(piehip_run(cc.handle())); }
+    void collect()
+    {
         const size_t ct = 2 * (size_t)cc.towers() * cc.ringDimension();
         std::vector<uint64_t> flat(ct * b);
         PieContext::check(piehip_get_results(cc.handle(), flat.data()));

@@ -40,6 +40,23 @@ int main()
         pie.setIndex(std::move(idx));
         pie.run();
         std::printf("facade ok: %zu result ciphertexts\n", pie.getResultList().size());
+        {
+            // a second query slot on the same database: the same query gives the same result list, evaluated concurrently
+            PieContext cc2(1024, 2, 65537);
+            BatchedFHEHIPPIE slot(cc2, pie);
+            std::vector<std::vector<LimbCt>> idx2(2, std::vector<LimbCt>(3));
+            for (auto &row : idx2)
+                for (auto &c : row) c.limbs.assign(ct, 5);
+            slot.setMinusCompareElement(minus);
+            slot.setIndex(std::move(idx2));
+            pie.enqueue();
+            slot.enqueue();
+            pie.collect();
+            slot.collect();
+            for (size_t i = 0; i < pie.getResultList().size(); i++)
+                if (pie.getResultList()[i].limbs != slot.getResultList()[i].limbs) return 4;
+            std::printf("query slot ok\n");
+        }
         // the rotation-based sibling (FHEHIPPIE.hpp): argument checks, then the reference call order
         CuckooTableView cv;
         cv.numberOfHashFunctions = 2, cv.binSize = 4, cv.eachTableSize = 4;
