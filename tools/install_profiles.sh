@@ -20,7 +20,7 @@ python - <<PY
 import json
 s = json.load(open("$P/summary.json"))
 s["config"] = "C3"
-s["source"] = ("profiles/$ROUND: tools/profile_round.sh -- rocprofv3 --kernel-trace --stats of 'python3 bench.py --streams 1 --no-cpu-baseline --no-e2e' "
+s["source"] = ("profiles/$ROUND: tools/profile_round.sh -- rocprofv3 --kernel-trace --stats of 'python3 bench.py --streams 1 --in-flight 1 --no-cpu-baseline --no-e2e' "
                "(kernel_stats) and separate --pmc FETCH_SIZE / WRITE_SIZE passes of the same command with --steps 5 --warmup 1 --profile-steps 1")
 json.dump(s, open("profiles/latest_pmc.json", "w"), indent=1, sort_keys=True)
 json.dump(s, open("$D/c3_summary.json", "w"), indent=1, sort_keys=True)
