@@ -137,6 +137,13 @@ int piehip_run_into(piehip_handle h, void *d_results);
  * pointers work. */
 int piehip_run_host(piehip_handle h, const uint64_t *idx /*[K][E][2][L][N]*/, const uint64_t *minus /*[2][L][N]*/,
                     uint64_t *results /*[b][2][L][N]*/);
+/* The same in two halves, for a server that keeps several queries in flight (one handle per query slot, see
+ * piehip_attach_database): _async returns once the uploads, the evaluation and the downloads are queued -- with page-locked
+ * arrays (piehip_host_buffers) nothing in it waits for the device -- and _wait blocks until `results` is complete.  While
+ * slot A evaluates, slot B's query crosses PCIe: the path is bound by the 29 MiB upload per query, not by upload + run +
+ * download.  The arrays must stay valid and unchanged until _wait returns. */
+int piehip_run_host_async(piehip_handle h, const uint64_t *idx, const uint64_t *minus, uint64_t *results);
+int piehip_run_host_wait(piehip_handle h);
 /* page-locked staging arrays owned by the handle (valid until the database shape changes or the handle is destroyed) */
 int piehip_host_buffers(piehip_handle h, uint64_t **idx, uint64_t **minus, uint64_t **results);
 /* Stream order.  run() works on the handle's own queues (piehip_set_run_streams); it waits for the handle's stream

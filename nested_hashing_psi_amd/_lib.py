@@ -44,6 +44,8 @@ SYMBOLS = {
     "piehip_join": (C.c_int, [C.c_void_p]),
     "piehip_run_into": (C.c_int, [C.c_void_p, C.c_void_p]),
     "piehip_run_host": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "piehip_run_host_async": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "piehip_run_host_wait": (C.c_int, [C.c_void_p]),
     "piehip_host_buffers": (C.c_int, [C.c_void_p, C.POINTER(u64p), C.POINTER(u64p), C.POINTER(u64p)]),
     "piehip_set_run_streams": (C.c_int, [C.c_void_p, C.c_uint32]),
     "piehip_set_graph": (C.c_int, [C.c_void_p, C.c_int]),

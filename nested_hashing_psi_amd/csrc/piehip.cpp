@@ -1278,7 +1278,7 @@ int piehip_host_buffers(piehip_handle h, uint64_t **idx, uint64_t **minus, uint6
     return PIEHIP_OK;
 }
 
-int piehip_run_host(piehip_handle h, const uint64_t *idx, const uint64_t *minus, uint64_t *results)
+int piehip_run_host_async(piehip_handle h, const uint64_t *idx, const uint64_t *minus, uint64_t *results)
 {
     if (!h) return fail(PIEHIP_EINVAL, "null handle");
     if (!idx || !minus) return fail(PIEHIP_EINVAL, "null input");
@@ -1323,11 +1323,24 @@ int piehip_run_host(piehip_handle h, const uint64_t *idx, const uint64_t *minus,
             HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_copy_gate, 0));
             HIPCHK(hipMemcpyAsync(results, h->d_out, (size_t)h->b * 2 * LN * sizeof(u64), hipMemcpyDeviceToHost, h->copy_stream));
         }
-        HIPCHK(hipStreamSynchronize(h->copy_stream));
     }
+    return PIEHIP_OK;
+}
+
+int piehip_run_host_wait(piehip_handle h)
+{
+    if (!h) return fail(PIEHIP_EINVAL, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->copy_stream) HIPCHK(hipStreamSynchronize(h->copy_stream));
     join_pending(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     return PIEHIP_OK;
+}
+
+int piehip_run_host(piehip_handle h, const uint64_t *idx, const uint64_t *minus, uint64_t *results)
+{
+    const int rc = piehip_run_host_async(h, idx, minus, results);
+    return rc ? rc : piehip_run_host_wait(h);
 }
 
 int piehip_join(piehip_handle h)

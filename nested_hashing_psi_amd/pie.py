@@ -330,6 +330,22 @@ class BatchedFHEHIPPIE:
         _check(lib().piehip_run_host(self.cc._h, ap, mp, results.ctypes.data_as(u64p)))
         return results
 
+    def runHostAsync(self, indexMatrix, minusCompareElement, results):
+        """queue runHost's uploads, evaluation and downloads and return (piehip_run_host_async); the three arrays -- page-locked
+        ones from hostBuffers() for a call that never waits -- must stay untouched until waitHost()"""
+        if indexMatrix.dtype != np.uint64 or not indexMatrix.flags.c_contiguous or minusCompareElement.dtype != np.uint64 \
+                or not minusCompareElement.flags.c_contiguous or results.dtype != np.uint64 or not results.flags.c_contiguous:
+            raise ValueError("runHostAsync needs contiguous uint64 arrays (no temporary copies may be taken)")
+        if indexMatrix.shape != (self.K, self.E, 2, self.cc.L, self.cc.N) or minusCompareElement.shape != (2, self.cc.L, self.cc.N) \
+                or results.shape != (self.b, 2, self.cc.L, self.cc.N):
+            raise ValueError("index matrix must be [K][E] ciphertexts, the minus element one ciphertext, results [b] ciphertexts")
+        _check(lib().piehip_run_host_async(self.cc._h, indexMatrix.ctypes.data_as(u64p), minusCompareElement.ctypes.data_as(u64p),
+                                           results.ctypes.data_as(u64p)))
+
+    def waitHost(self):
+        """block until the results of the last runHostAsync are complete in host memory"""
+        _check(lib().piehip_run_host_wait(self.cc._h))
+
     def join(self):
         """order the context's stream behind the runs queued so far (no host wait)"""
         _check(lib().piehip_join(self.cc._h))

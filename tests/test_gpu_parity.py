@@ -562,6 +562,19 @@ def test_query_slots_on_one_database(ob, pie, N, L, K, E, b, depth):
         pipe.sync()
         for s, (idx, minus) in zip(pipe.slots, queries):
             assert (s.getResultList() == o.pie_run(idx, minus, db, masks, evk)).all()
+    # the host-memory form of the same: each slot's query uploads, evaluates and downloads on its own queues
+    # (piehip_run_host_async / _wait), page-locked staging, all slots queued before the first wait
+    bufs = [s.hostBuffers() for s in pipe.slots]
+    for rnd in range(2):
+        queries = [(rand_limbs(rng, cc.q, (K, E, 2), N), rand_limbs(rng, cc.q, (2,), N)) for _ in range(depth)]
+        for s, (pi, pm, pr), (idx, minus) in zip(pipe.slots, bufs, queries):
+            pi[...] = idx
+            pm[...] = minus
+            pr[...] = 0
+            s.runHostAsync(pi, pm, pr)
+        for s, (pi, pm, pr), (idx, minus) in zip(pipe.slots, bufs, queries):
+            s.waitHost()
+            assert (pr == o.pie_run(idx, minus, db, masks, evk)).all()
     with pytest.raises(ValueError):
         pipe.slots[1].cc.load_relin_key(evk)
     # a slot with a database of its own: detached, the owner's buffers untouched
