@@ -165,9 +165,10 @@ int piehip_set_graph(piehip_handle h, int on);
  * database and masks by reference -- nothing is copied -- and gets a run() workspace of its own, so that queries set and
  * run on the two handles (each on its own stream) overlap: one query's plaintext-ciphertext stage is HBM-bound while the
  * other's transforms are ALU-bound.  The reference operator evaluates one query at a time (BatchedFHEHIPPIE.cpp:88-129);
- * this is how a server with several clients keeps the GPU full.  `owner` must outlive `h` and must not reload its key or
- * database while `h` is in use; loading a key or database into `h` itself returns it to a private copy (load_relin_key is
- * refused while attached). */
+ * this is how a server with several clients keeps the GPU full.  While handles are attached, `owner` refuses to be
+ * destroyed or to load a database of another shape (PIEHIP_ESTATE); reloading a key or a same-shape database into it
+ * rewrites the shared buffers in place, so do that only between queries.  Loading a database into `h` itself returns it to a
+ * private copy (load_relin_key is refused while attached). */
 int piehip_attach_database(piehip_handle h, piehip_handle owner);
 /* getResultList (BatchedFHEHIPPIE.hpp:35-38): out[b][2][L][N] */
 int piehip_get_results(piehip_handle h, uint64_t *out);

@@ -115,6 +115,8 @@ struct piehip_ctx {
     NttPlan plan;
     // keys / database / inputs
     bool db_borrowed = false;  // piehip_attach_database: d_evk*, d_db, d_masks* belong to another handle (never freed or written here)
+    piehip_ctx *db_owner = nullptr;  // ... that handle
+    u32 db_borrowers = 0;            // handles that borrow from this one: its buffers may not move while > 0
     u64 *d_evk = nullptr;
     u32 K = 0, b = 0, E = 0;
     u64 *d_db = nullptr, *d_masks = nullptr;
@@ -556,11 +558,14 @@ static void detach_database(piehip_ctx *h)
     if (!h->db_borrowed) return;
     h->d_evk = h->d_evk_sigma = h->d_db = h->d_masks = h->d_masks_sigma = nullptr;
     h->db_borrowed = false;
+    if (h->db_owner && h->db_owner->db_borrowers) h->db_owner->db_borrowers--;
+    h->db_owner = nullptr;
 }
 
 int piehip_destroy(piehip_handle h)
 {
     if (!h) return PIEHIP_OK;
+    if (h->db_borrowers) return fail(PIEHIP_ESTATE, "destroy: other handles still use this handle's database (destroy them first)");
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->pool) (void)hipEventDestroy(e);
@@ -699,6 +704,7 @@ static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E, bool with_db = 
         h->d_idx = nullptr;
         return PIEHIP_OK;
     }
+    if (h->db_borrowers) return fail(PIEHIP_ESTATE, "a database of another shape cannot be loaded while other handles are attached to this one");
     dev_free(&h->d_db);
     dev_free(&h->d_masks);
     dev_free(&h->d_masks_sigma);
@@ -771,6 +777,8 @@ int piehip_attach_database(piehip_handle h, piehip_handle owner)
     h->d_masks = owner->d_masks;
     h->d_masks_sigma = owner->d_masks_sigma;
     h->db_borrowed = true;
+    h->db_owner = owner;
+    owner->db_borrowers++;
     return PIEHIP_OK;
 }
 

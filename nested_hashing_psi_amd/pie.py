@@ -72,13 +72,18 @@ class PieContext:
     def close(self):
         if getattr(self, "_h", None):
             try:
-                lib().piehip_destroy(self._h)
+                rc = lib().piehip_destroy(self._h)
             except TypeError:  # interpreter shutdown: module globals already cleared
-                pass
+                rc = 0
+            if rc:          # refused: query slots are still attached to this context's database (close them first)
+                _check(rc)
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except RuntimeError:
+            pass
 
     # -- tables (for cross-checks)
     def psi(self, mi):

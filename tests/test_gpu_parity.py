@@ -577,6 +577,8 @@ def test_query_slots_on_one_database(ob, pie, N, L, K, E, b, depth):
             assert (pr == o.pie_run(idx, minus, db, masks, evk)).all()
     with pytest.raises(ValueError):
         pipe.slots[1].cc.load_relin_key(evk)
+    with pytest.raises(RuntimeError):   # the owner's buffers may not move while slots are attached
+        pie.BatchedFHEHIPPIE(cc, vectorizedHCT=rand_limbs(rng, cc.q, (K, 2, E), N), preCalcRandomMask=rand_limbs(rng, cc.q, (2,), N))
     # a slot with a database of its own: detached, the owner's buffers untouched
     db2, masks2 = rand_limbs(rng, cc.q, (K, 3, E), N), rand_limbs(rng, cc.q, (3,), N)
     c1 = pipe.slots[1].cc
