@@ -241,6 +241,53 @@ __device__ __forceinline__ Mod ld_mod(DcC c, u32 i)
     return m;
 }
 
+// Conditional subtraction with a wave-uniform modulus, without VCC: t = x - m as x + (2^64 - m) (one v_lshl_add_u64 with the
+// negated modulus in scalar registers), then a select on the sign of t (v_ashrrev_i32 + two v_bfi_b32).  hipcc's lowering of
+// `x >= m ? x - m : x` is compare + two moves of the modulus into vector registers + two v_cndmask + a two-instruction
+// subtraction through VCC with its wait state: 8 instructions against 4, ~120 times per coefficient pair of a base conversion.
+// Needs x < 2^63 and x - m > -2^63 (all residues here are below 2^62).
+__device__ __forceinline__ u64 neg_u(u64 m)  // 2^64 - m, kept opaque so that x + neg_u(m) stays an addition
+{
+    u64 n = 0 - m;
+    asm("" : "+s"(n));
+    return n;
+}
+__device__ __forceinline__ u64 sel_neg(u64 x, u64 t, u32 &mask)  // t < 0 ? x : t;  mask = t < 0 ? ~0 : 0
+{
+    u32 lo, hi, k;
+    asm("v_ashrrev_i32 %[k], 31, %[th]\n\t"
+        "v_bfi_b32 %[lo], %[k], %[xl], %[tl]\n\t"
+        "v_bfi_b32 %[hi], %[k], %[xh], %[th]"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [k] "=&v"(k)
+        : [xl] "v"((u32)x), [xh] "v"((u32)(x >> 32)), [tl] "v"((u32)t), [th] "v"((u32)(t >> 32)));
+    mask = k;
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 csub_u(u64 x, u64 negm)
+{
+    u32 k;
+    return sel_neg(x, x + negm, k);
+}
+// the modarith.h formulas with this subtraction (same values; moduli wave-uniform: they come from ld_mod / scalar loads)
+__device__ __forceinline__ u64 mul_shoup_lazy_u(u64 a, u64 w, u64 wsh, u64 q) { return a * w - mulhi(a, wsh) * q; }
+__device__ __forceinline__ u64 mul_shoup_u(u64 a, u64 w, u64 wsh, u64 q, u64 negq) { return csub_u(mul_shoup_lazy_u(a, w, wsh, q), negq); }
+__device__ __forceinline__ u64 fixfrac_u(u64 y, const Mod &m) { return mulhi(y << m.fshift, m.fconst) >> 3; }
+__device__ __forceinline__ void divmod_shoup_u(u64 a, u64 w, u64 wsh, u64 q, u64 negq, u64 &quot, u64 &rem)
+{
+    const u64 qe = mulhi(a, wsh);
+    const u64 r = a * w - qe * q;
+    u32 k;
+    rem = sel_neg(r, r + negq, k);
+    quot = qe + 1 + (u64)(int64_t)(int32_t)k;  // + 1 unless r < q
+}
+__device__ __forceinline__ u64 reduce123_u(U128 z, const Mod &m, u64 negq, u64 neg2q)
+{
+    const u64 mu = (m.r1 << 59) | (m.r0 >> 5);
+    const u64 zh = (z.hi << 5) | (z.lo >> 59);
+    const u64 qhat = mulhi(zh, mu);
+    return csub_u(csub_u(z.lo - qhat * m.q, neg2q), negq);
+}
+
 // sum_i y[i] * c[i] as a 128-bit integer.  MAD: carry-free column accumulators on v_mad_u64_u32 (madasm.h; needs all
 // operands < 2^60 and NS <= 8), otherwise 64x64->128 multiplies.
 template <u32 NS, bool MAD>
@@ -261,12 +308,12 @@ __device__ __forceinline__ U128 dot128(const u64 *y, const u64 (&c)[NS])
 // centred CRT lift of y_i-weighted residues from a source basis into target modulus `tm`:
 //   sum_i y_i * hat[i] - v * prodmod
 template <u32 NS, bool MAD>
-__device__ __forceinline__ u64 crt_out(const u64 *y, const u64 (&hat)[NS], u64 v, u64 prodmod, const Mod &tm)
+__device__ __forceinline__ u64 crt_out(const u64 *y, const u64 (&hat)[NS], u64 v, u64 prodmod, const Mod &tm, u64 negq, u64 neg2q)
 {
     U128 acc = dot128<NS, MAD>(y, hat);
     mac128(acc, v, tm.q - prodmod);  // - v * prodmod (mod tm); v <= ns: one Barrett reduction for the whole sum
     // MAD implies 2^59 < q < 2^60 for every modulus: up to 7 products plus the small terms stay below 2^123
-    return (MAD && NS <= 7) ? reduce123(acc, tm) : reduce128(acc, tm);
+    return (MAD && NS <= 7) ? reduce123_u(acc, tm, negq, neg2q) : reduce128(acc, tm);
 }
 
 // Outer-stage folding.  For N >= 2^14 the transforms next to these kernels run as two half-size slices per limb
@@ -280,16 +327,16 @@ __device__ __forceinline__ void fold_load(const DevConsts *dc, u32 a, u64 u, u64
 {
     PIE_ITER_FENCE();
     const DcC c = dc_iter(dc);
-    const u64 q = c->mod[a].q;
-    x0 = mul_shoup(u + v, c->fold_ia[a], c->fold_ia_sh[a], q);
-    x1 = mul_shoup(u + (4 * q - v), c->fold_ib[a], c->fold_ib_sh[a], q);
+    const u64 q = c->mod[a].q, nq = neg_u(q);
+    x0 = mul_shoup_u(u + v, c->fold_ia[a], c->fold_ia_sh[a], q, nq);
+    x1 = mul_shoup_u(u + (4 * q - v), c->fold_ib[a], c->fold_ib_sh[a], q, nq);
 }
 // u canonical; results in (0, 3q)
 __device__ __forceinline__ void fold_store(const DevConsts *dc, u32 a, u64 u, u64 v, u64 &y0, u64 &y1)
 {
     const DcC c = dc_iter(dc);
     const u64 q = c->mod[a].q;
-    const u64 t = mul_shoup_lazy(v, c->fold_w[a], c->fold_w_sh[a], q);  // [0, 2q)
+    const u64 t = mul_shoup_lazy_u(v, c->fold_w[a], c->fold_w_sh[a], q);  // [0, 2q)
     y0 = u + t;
     y1 = u + (2 * q - t);
 }
@@ -313,12 +360,12 @@ __device__ __forceinline__ void expand_core(const DevConsts *dc, const u64 (&x)[
         PIE_ITER_FENCE();
         const DcC c = dc_iter(dc);
         const Mod mi = ld_mod(c, i);
-        const u64 w = c->qhat_inv[i], wsh = c->qhat_inv_sh[i];
+        const u64 w = c->qhat_inv[i], wsh = c->qhat_inv_sh[i], nq = neg_u(mi.q);
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             out[p][i] = x[p][i];
-            y[p][i] = YIN ? x[p][i] : mul_shoup(x[p][i], w, wsh, mi.q);
-            fsum[p] += fixfrac(y[p][i], mi);
+            y[p][i] = YIN ? x[p][i] : mul_shoup_u(x[p][i], w, wsh, mi.q, nq);
+            fsum[p] += fixfrac_u(y[p][i], mi);
         }
     }
 #pragma unroll
@@ -329,9 +376,9 @@ __device__ __forceinline__ void expand_core(const DevConsts *dc, const u64 (&x)[
         u64 hat[L];
 #pragma unroll
         for (u32 i = 0; i < L; i++) hat[i] = c->qhat_modp[i][j];
-        const u64 prodmod = c->Q_modp[j];
+        const u64 prodmod = c->Q_modp[j], nq = neg_u(pj.q), n2q = neg_u(2 * pj.q);
 #pragma unroll
-        for (int p = 0; p < NP; p++) out[p][L + j] = crt_out<L, MAD>(y[p], hat, (fsum[p] + FIX_HALF) >> 60, prodmod, pj);
+        for (int p = 0; p < NP; p++) out[p][L + j] = crt_out<L, MAD>(y[p], hat, (fsum[p] + FIX_HALF) >> 60, prodmod, pj, nq, n2q);
     }
 }
 
@@ -350,15 +397,15 @@ __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 (&x
         PIE_ITER_FENCE();
         const DcC c = dc_iter(dc);
         const Mod mi = ld_mod(c, i);
-        const u64 w = c->qhat_inv[i], wsh = c->qhat_inv_sh[i], pw = c->P_modq[i], pwsh = c->P_modq_sh[i];
+        const u64 w = c->qhat_inv[i], wsh = c->qhat_inv_sh[i], pw = c->P_modq[i], pwsh = c->P_modq_sh[i], nq = neg_u(mi.q);
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            y[p][i] = YIN ? x[p][i] : mul_shoup(x[p][i], w, wsh, mi.q);
+            y[p][i] = YIN ? x[p][i] : mul_shoup_u(x[p][i], w, wsh, mi.q, nq);
             // y_i P / q_i = y_i floor(P/q_i) + floor(y_i w_i / q_i) + (y_i w_i mod q_i) / q_i
             u64 fl, z;
-            divmod_shoup(y[p][i], pw, pwsh, mi.q, fl, z);
+            divmod_shoup_u(y[p][i], pw, pwsh, mi.q, nq, fl, z);
             add128(itot[p], U128{fl, 0});
-            fsum[p] += fixfrac(z, mi);
+            fsum[p] += fixfrac_u(z, mi);
         }
     }
     u64 yp[NP][Lp];
@@ -376,15 +423,15 @@ __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 (&x
         u64 col[L];
 #pragma unroll
         for (u32 i = 0; i < L; i++) col[i] = c->PI_modp[i][j];
-        const u64 w = c->phat_inv[j], wsh = c->phat_inv_sh[j];
+        const u64 w = c->phat_inv[j], wsh = c->phat_inv_sh[j], nq = neg_u(pj.q), n2q = neg_u(2 * pj.q);
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             U128 acc = dot128<L, MAD>(y[p], col);
             add128(acc, itot[p]);
-            const u64 r = MAD ? reduce123(acc, pj) : reduce128(acc, pj);  // L <= 7 products + a 64-bit term
+            const u64 r = MAD ? reduce123_u(acc, pj, nq, n2q) : reduce128(acc, pj);  // L <= 7 products + a 64-bit term
             out[p][L + j] = r;
-            yp[p][j] = mul_shoup(r, w, wsh, pj.q);
-            fs2[p] += fixfrac(yp[p][j], pj);
+            yp[p][j] = mul_shoup_u(r, w, wsh, pj.q, nq);
+            fs2[p] += fixfrac_u(yp[p][j], pj);
         }
     }
 #pragma unroll
@@ -395,9 +442,9 @@ __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 (&x
         u64 hat[Lp];
 #pragma unroll
         for (u32 j = 0; j < Lp; j++) hat[j] = c->phat_modq[j][i];
-        const u64 prodmod = c->P_modq[i];
+        const u64 prodmod = c->P_modq[i], nq = neg_u(mi.q), n2q = neg_u(2 * mi.q);
 #pragma unroll
-        for (int p = 0; p < NP; p++) out[p][i] = crt_out<Lp, MAD>(yp[p], hat, (fs2[p] + FIX_HALF) >> 60, prodmod, mi);
+        for (int p = 0; p < NP; p++) out[p][i] = crt_out<Lp, MAD>(yp[p], hat, (fs2[p] + FIX_HALF) >> 60, prodmod, mi, nq, n2q);
     }
 }
 
@@ -422,9 +469,9 @@ __global__ void __launch_bounds__(TPB) expand_kernel(const DevConsts *__restrict
         if (YIN) {
             PIE_ITER_FENCE();
             const DcC c = dc_iter(dc);
-            const u64 q = c->mod[i].q, u = pin[(size_t)i * N], v = pin[(size_t)i * N + H];
-            x[0][i] = mul_shoup(u + v, c->fold_iaq[i], c->fold_iaq_sh[i], q);            // u, v in [0, 4q)
-            x[NP - 1][i] = mul_shoup(u + (4 * q - v), c->fold_ibq[i], c->fold_ibq_sh[i], q);
+            const u64 q = c->mod[i].q, nq = neg_u(q), u = pin[(size_t)i * N], v = pin[(size_t)i * N + H];
+            x[0][i] = mul_shoup_u(u + v, c->fold_iaq[i], c->fold_iaq_sh[i], q, nq);            // u, v in [0, 4q)
+            x[NP - 1][i] = mul_shoup_u(u + (4 * q - v), c->fold_ibq[i], c->fold_ibq_sh[i], q, nq);
         } else if (FOLD) {
             fold_load(dc, i, pin[(size_t)i * N], pin[(size_t)i * N + H], x[0][i], x[NP - 1][i]);
         } else {
@@ -530,14 +577,14 @@ __device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 
         PIE_ITER_FENCE();
         const DcC c = dc_iter(dc);
         const Mod pj = ld_mod(c, L + j);
-        const u64 w = c->qp_hat_inv[L + j], wsh = c->qp_hat_inv_sh[L + j], tw = c->tQ_modp[j], twsh = c->tQ_modp_sh[j];
+        const u64 w = c->qp_hat_inv[L + j], wsh = c->qp_hat_inv_sh[L + j], tw = c->tQ_modp[j], twsh = c->tQ_modp_sh[j], nq = neg_u(pj.q);
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            yp[p][j] = mul_shoup(d[p][L + j], w, wsh, pj.q);
+            yp[p][j] = mul_shoup_u(d[p][L + j], w, wsh, pj.q, nq);
             u64 fl, z;
-            divmod_shoup(yp[p][j], tw, twsh, pj.q, fl, z);
+            divmod_shoup_u(yp[p][j], tw, twsh, pj.q, nq, fl, z);
             add128(itot[p], U128{fl, 0});
-            fsum[p] += fixfrac(z, pj);
+            fsum[p] += fixfrac_u(z, pj);
         }
     }
 #pragma unroll
@@ -550,13 +597,13 @@ __device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 
         u64 col[Lp];
 #pragma unroll
         for (u32 j = 0; j < Lp; j++) col[j] = c->tQF_modq[j][k];
-        const u64 tp = c->tPinv_modq[k];
+        const u64 tp = c->tPinv_modq[k], nq = neg_u(qk.q), n2q = neg_u(2 * qk.q);
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             U128 acc = dot128<Lp, MAD>(yp[p], col);
             mac128(acc, d[p][k], tp);
             add128(acc, itot[p]);
-            out[p][k] = (MAD && L <= 5) ? reduce123(acc, qk) : reduce128(acc, qk);  // L + 2 products
+            out[p][k] = (MAD && L <= 5) ? reduce123_u(acc, qk, nq, n2q) : reduce128(acc, qk);  // L + 2 products
         }
     }
 }

@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import bench
+if "PIEHIP_AB_LIB" in os.environ:   # A/B of two builds inside one gpurun call (boxes differ by several percent)
+    import nested_hashing_psi_amd._lib as _L
+    _L.LIB_PATH = os.path.abspath(os.environ["PIEHIP_AB_LIB"])
 from nested_hashing_psi_amd import pie
 
 E, bl = int(sys.argv[1]), int(sys.argv[2])
