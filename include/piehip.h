@@ -112,6 +112,11 @@ int piehip_load_db_table_bins(piehip_handle h, const uint64_t *tbl, uint32_t k, 
 int piehip_get_hash_table(piehip_handle h, uint64_t *tbl);
 /* TabulationHashing::hashWithIndicator for n inputs (host-side; no device needed) */
 int piehip_tabulation_hash(uint64_t hash_seed, uint32_t nfun, uint32_t hf, const uint64_t *x, size_t n, uint64_t *out);
+/* the client's Cuckoo table (client harness; host-side): k single-layer tables of e positions, hash functions 0..k-1 of the
+ * nfun-function family, items inserted in order with the reference's eviction walk (BatchedFHEPSIClient.cpp:97-99,109;
+ * CuckooHashTable.cpp:72-114).  table[k][e], 0 = empty.  PIEHIP_EHASH when an insertion fails after 1000 retries. */
+int piehip_client_cuckoo_table(uint64_t hash_seed, uint32_t nfun, uint32_t k, uint32_t e, const uint64_t *items, size_t n,
+                               uint64_t *table);
 
 /* setIndex (BatchedFHEHIPPIE.hpp:40-43): idx[K][E][2][L][N];
  * setMinusCompareElement (BatchedFHEHIPPIE.hpp:45-48): minus[2][L][N]. */

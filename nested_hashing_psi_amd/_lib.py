@@ -35,6 +35,7 @@ SYMBOLS = {
     "piehip_reserve": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_uint32] * 7),
     "piehip_get_hash_table": (C.c_int, [C.c_void_p, u64p]),
     "piehip_tabulation_hash": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, u64p, C.c_size_t, u64p]),
+    "piehip_client_cuckoo_table": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, u64p, C.c_size_t, u64p]),
     "piehip_set_index": (C.c_int, [C.c_void_p, u64p]),
     "piehip_set_minus": (C.c_int, [C.c_void_p, u64p]),
     "piehip_set_index_device": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -76,27 +76,9 @@ class BatchedFHEPSIClient:
     #    (BatchedFHEPSIClient.cpp:97-99, insertAll at :109; insert at CuckooHashTable.cpp:72-114)
     def _hash_client_set(self, items):
         items = np.ascontiguousarray(items, dtype=np.uint64)
-        k, e = self.k, self.e
-        pos = np.stack([tabulation_hash(self.hashSeed, k + self.K, hf, items) % np.uint64(e) for hf in range(k)])
-        where = {int(x): i for i, x in enumerate(items)}
-        table = np.zeros((k, e), dtype=np.uint64)
-        for a, x in enumerate(items):
-            x = int(x)
-            if any(int(table[hf, pos[hf, where[x]]]) == x for hf in range(k)):  # lookUp: duplicate
-                continue
-            placed = False
-            for _ in range(1000):                                  # numberOfRetries
-                for hf in range(k):
-                    p = int(pos[hf, where[x]]) if x in where else int(tabulation_hash(self.hashSeed, k + self.K, hf, [x])[0] % e)
-                    if table[hf, p] == 0:
-                        table[hf, p] = x
-                        placed = True
-                        break
-                    x, table[hf, p] = int(table[hf, p]), x         # one layer: evict the occupant
-                if placed:
-                    break
-            if not placed:
-                raise RuntimeError("(Blocked) Cuckoo hashing error")
+        table = np.zeros((self.k, self.e), dtype=np.uint64)
+        _check(lib().piehip_client_cuckoo_table(self.hashSeed, self.k + self.K, self.k, self.e, items.ctypes.data_as(u64p), len(items),
+                                                table.ctypes.data_as(u64p)))
         return table
 
     # -- offline (BatchedFHEPSIClient.cpp:107-169): index matrix + minus vector, secret-key encrypted

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.hpp"
@@ -887,6 +888,46 @@ int piehip_tabulation_hash(uint64_t hash_seed, uint32_t nfun, uint32_t hf, const
             v >>= 8;
         }
         out[a] = res;
+    }
+    return PIEHIP_OK;
+}
+
+// The client's table (host side, no device): CuckooHashTable(hash, e, k, startingHashId 0, stash 0, multi tables, 1 layer),
+// insertAll (BatchedFHEPSIClient.cpp:97-99,109; insert / eviction walk at CuckooHashTable.cpp:72-114, 1000 retries).
+int piehip_client_cuckoo_table(uint64_t hash_seed, uint32_t nfun, uint32_t k, uint32_t e, const uint64_t *items, size_t n,
+                               uint64_t *table)
+{
+    if (!items || !table || !k || !e || k > nfun) return fail(PIEHIP_EINVAL, "bad argument");
+    std::vector<u64> tab;
+    tabulation_tables(hash_seed, nfun, tab);
+    auto pos = [&](u64 x, u32 hf) -> size_t {
+        const u64 *t = tab.data() + (size_t)hf * 16 * 256;
+        u64 v = x, res = 0;
+        for (int i = 0; i < 16; i++) {
+            res ^= t[i * 256 + (v & 0xff)];
+            v >>= 8;
+        }
+        return (size_t)(res % e);
+    };
+    std::fill(table, table + (size_t)k * e, 0);
+    for (size_t a = 0; a < n; a++) {
+        u64 x = items[a];
+        bool dup = false;
+        for (u32 hf = 0; hf < k; hf++) dup = dup || table[(size_t)hf * e + pos(x, hf)] == x;  // lookUp
+        if (dup) continue;
+        bool placed = false;
+        for (int retry = 0; retry < 1000 && !placed; retry++) {  // numberOfRetries
+            for (u32 hf = 0; hf < k; hf++) {
+                u64 &slot = table[(size_t)hf * e + pos(x, hf)];
+                if (slot == 0) {
+                    slot = x;
+                    placed = true;
+                    break;
+                }
+                std::swap(x, slot);  // one layer: evict the occupant and carry it to the next table
+            }
+        }
+        if (!placed) return fail(PIEHIP_EHASH, "(Blocked) Cuckoo hashing error");
     }
     return PIEHIP_OK;
 }
@@ -1993,12 +2034,24 @@ int piehip_client_encrypt(piehip_handle h, const uint64_t *sk, const int64_t *sl
         if ((u64)(slots[i] < 0 ? -slots[i] : slots[i]) >= t) return fail(PIEHIP_EINVAL, "slot value out of range for the plaintext modulus");
     std::vector<u64> cts((size_t)nct * 2 * LN);
     std::vector<int32_t> ev((size_t)nct * N);
-    for (u32 c = 0; c < nct; c++) {  // same stream order as a sequential client: a (uniform), then e
-        HostRng r(seeds[c]);
-        sample_uniform(r, h->hp, &cts[(size_t)c * 2 * LN + LN]);
-        sample_error(r, N, &ev[(size_t)c * N]);
+    {
+        // every ciphertext has its own seed and draws a (uniform), then e, as a sequential client would: the ciphertexts are
+        // independent, so host threads share them out (2.4 M rejection-sampled words for the 29 ciphertexts of a C3 query)
+        auto sample = [&](u32 c0, u32 c1) {
+            for (u32 c = c0; c < c1; c++) {
+                HostRng r(seeds[c]);
+                sample_uniform(r, h->hp, &cts[(size_t)c * 2 * LN + LN]);
+                sample_error(r, N, &ev[(size_t)c * N]);
+            }
+        };
+        const u32 hw = std::thread::hardware_concurrency();
+        const u32 nth = std::max(1u, std::min(std::min(nct, hw ? hw : 1u), 16u));
+        std::vector<std::thread> pool;
+        for (u32 i = 1; i < nth; i++) pool.emplace_back(sample, (u32)((u64)nct * i / nth), (u32)((u64)nct * (i + 1) / nth));
+        sample(0, nct / nth);
+        for (auto &th : pool) th.join();
     }
-    Tmp tmp;
+    Tmp tmp(h);
     TMPGET(d_out, cts.size());
     TMPGET(d_sk, LN);
     TMPGET(d_slotsw, (size_t)nct * B);

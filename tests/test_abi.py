@@ -87,6 +87,27 @@ def test_tabulation_hash_matches_oracle(built, ob):
             assert [int(v) for v in got] == [tab.hash(int(v), hf) for v in x]
 
 
+def test_client_cuckoo_table_matches_oracle(built, ob):
+    """piehip_client_cuckoo_table (host side, no device) == the oracle's client table, on loads that force eviction walks,
+    with duplicates, and the failure when the set cannot be placed"""
+    import ctypes as C
+    from nested_hashing_psi_amd._lib import lib, u64p
+    from tests.test_oracle_pie import distinct_items
+    rng = np.random.default_rng(9)
+    for (k, e, n, K) in ((2, 20, 12, 2), (2, 64, 90, 2), (3, 40, 100, 2), (2, 4949, 1024, 2)):
+        items = distinct_items(rng, 4296540161, n)
+        items = np.concatenate([items, items[:3]])                 # duplicates are skipped
+        tab = ob.Tabulation(987654321, k + K)
+        want = ob.client_build(tab, items, k, e)
+        got = np.zeros((k, e), dtype=np.uint64)
+        rc = lib().piehip_client_cuckoo_table(987654321, k + K, k, e, items.ctypes.data_as(u64p), len(items), got.ctypes.data_as(u64p))
+        assert rc == 0 and (got == want).all()
+        assert np.count_nonzero(got) == n
+    items = distinct_items(rng, 65537, 9)                          # 9 items into 2 x 4 positions
+    got = np.zeros((2, 4), dtype=np.uint64)
+    assert lib().piehip_client_cuckoo_table(1, 4, 2, 4, items.ctypes.data_as(u64p), len(items), got.ctypes.data_as(u64p)) == -5
+
+
 def test_bench_algorithmic_bytes_follow_the_survey():
     """one run() of the reference schedule moves 253 + 14 * 54 + 35 = 1044 MiB at C3 (unfused limb passes)"""
     import bench
