@@ -290,7 +290,7 @@ def time_slots(ops, steps, warmup, sync):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-PROJECTION_IN_FLIGHT = 6
+PROJECTION_IN_FLIGHT = 3
 
 
 def projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, steps, warmup):
@@ -378,7 +378,7 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
     # slot B's 29 MiB cross PCIe while slot A evaluates, so a query costs its upload, not upload + run + download
     pipelined = None
     if more_ops:
-        allops = [op] + [m[0] for m in more_ops]
+        allops = [op, more_ops[0][0]]   # two slots: a third one's upload only competes for the link (measured: 0.70 vs 1.09 ms)
         for o in allops:
             o.cc.set_run_streams(2)   # two queues per run(): each group's results leave as soon as it is done (measured: 0.70 vs 1.09 ms)
         bufs = [o.hostBuffers() for o in allops]
@@ -411,7 +411,7 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
     mib = (idx_h.nbytes + minus_h.nbytes) / 2**20
     out = {}
     if pipelined is not None:
-        out = {"run_host_async_stream_ms_per_query": pipelined * 1e3, "run_host_async_slots": 1 + len(more_ops),
+        out = {"run_host_async_stream_ms_per_query": pipelined * 1e3, "run_host_async_slots": 2,
                "value_run_host_async_stream": b / pipelined}
     return {**out, "unit": "ms", "iters": iters,
             "separate_calls_ms": sep * 1e3, "separate_calls_with_results_ms": sep_res * 1e3,
@@ -440,7 +440,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="run() as one captured hipGraph (piehip_set_graph)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="queries in flight: query slots (own stream + workspace, one shared database: piehip_attach_database) that "
-                         "run() round-robin.  0 = default (2; 6 for a rank's share of fewer than 8 bin layers), 1 = one query at a time")
+                         "run() round-robin.  0 = default (3: one hardware queue each on a runtime with four), 1 = one query at a time")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams run() spreads the bin layers over (0 = library default, 1 = serial: every kernel alone on the GPU)")
     ap.add_argument("--collective", default="auto", choices=["auto", "gather", "all_gather"],
@@ -508,8 +508,9 @@ def main():
     # of bin layers leaves most of the chip idle: further query slots (a context with its own stream and run() workspace,
     # reading slot 0's key and database by reference) take the steps round-robin.  Every step is still one full run() over
     # its own inputs into its own result buffer.  With slots, one queue per run() is the faster setting (measured).
-    share = -(-b_total // world) if (scaling == "strong" and world > 1) else b_local   # the same on every rank
-    in_flight = args.in_flight or (2 if share >= 8 else 6)
+    # three: the HIP runtime multiplexes streams onto four hardware queues, and streams that share one serialise (measured:
+    # 2 / 3 / 4 / 6 slots -> 259 / 249 / 264 / 252 us per C3 query, 76 / 59 / 74 / 63 us per query of a 2-layer share)
+    in_flight = args.in_flight or 3
     if args.graph:
         in_flight = 1
     run_streams = args.streams or (1 if in_flight > 1 else 0)

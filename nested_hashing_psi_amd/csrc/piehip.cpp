@@ -429,18 +429,7 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
         CHK_(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->own_stream = true;
     }
-    {
-        const int ns = 2;  // queues of run(): see piehip_run_into (3 is equal within noise, 4 and more collapse)
-        CHK_(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        for (int i = 0; i < ns; i++) {
-            hipStream_t s = nullptr;
-            hipEvent_t e = nullptr;
-            CHK_(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-            h->side_streams.push_back(s);
-            CHK_(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            h->ev_join.push_back(e);
-        }
-    }
+    CHK_(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     const u32 M = h->hp.M;
     CHK_(hipMalloc((void **)&h->d_dc, sizeof(DevConsts)));
     CHK_(hipMemcpy(h->d_dc, &h->hp.dc, sizeof(DevConsts), hipMemcpyHostToDevice));
@@ -1109,11 +1098,26 @@ int piehip_set_minus_device(piehip_handle h, const void *d_minus)
 // Queues of a run().  The default is two when the handle evaluates enough bin layers to fill the chip twice over; below that
 // every launch is bound by its own latency, a second queue only interleaves two latency-bound chains on the same CUs, and one
 // queue is faster (measured at the C3 ring: 2 layers 115 vs 146 us, 5 layers of the E = 40 row 217 vs 239 us, 7 layers even).
+static const u32 MAX_RUN_QUEUES = 2;  // 3 is equal within noise, 4 and more collapse
 static u32 run_queue_count(const piehip_ctx *h)
 {
-    const size_t nq = h->side_streams.size();
     const u32 want = h->run_streams ? h->run_streams : (h->b >= 8 ? 2u : 1u);
-    return (u32)std::min<size_t>(want, std::min<size_t>(nq, h->b));
+    return std::min(want, std::min(MAX_RUN_QUEUES, h->b));
+}
+// The queues are created when a run first needs them: a handle that runs on one queue (a query slot, a rank's small share)
+// then owns one stream, not three -- the runtime multiplexes streams onto a few hardware queues, and streams that share one
+// serialise against each other.
+static int ensure_run_queues(piehip_ctx *h, u32 ng)
+{
+    while (h->side_streams.size() < ng) {
+        hipStream_t s = nullptr;
+        hipEvent_t e = nullptr;
+        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        h->side_streams.push_back(s);
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->ev_join.push_back(e);
+    }
+    return PIEHIP_OK;
 }
 
 // bin layers of queue group g of ng.  Two groups take 4/7 and 3/7 of the layers: measured 3.5 % faster than equal halves at
@@ -1202,6 +1206,10 @@ int piehip_run_into(piehip_handle h, void *d_results)
     //   * the handle's stream joins the queues lazily, in the next entry point that is not a run (NEED / piehip_join),
     //     so back-to-back runs of one query batch keep every queue busy across run boundaries.
     const u32 ng = run_queue_count(h);
+    if (ng > 1) {
+        const int qrc = ensure_run_queues(h, ng);
+        if (qrc) return qrc;
+    }
     if (h->use_graph && !h->profiling && !h->row_events) {
         // One graph launch instead of ~13 kernel launches and 2 event operations per queue group: the same two chains, forked
         // from and joined back to the handle's stream inside the graph (so consecutive runs do not overlap each other, which
