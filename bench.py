@@ -378,9 +378,7 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
     # slot B's 29 MiB cross PCIe while slot A evaluates, so a query costs its upload, not upload + run + download
     pipelined = None
     if more_ops:
-        allops = [op, more_ops[0][0]]   # two slots: a third one's upload only competes for the link (measured: 0.70 vs 1.09 ms)
-        for o in allops:
-            o.cc.set_run_streams(2)   # two queues per run(): each group's results leave as soon as it is done (measured: 0.70 vs 1.09 ms)
+        allops = [op] + [m[0] for m in more_ops]   # every query slot, one queue per run() as in the timed region
         bufs = [o.hostBuffers() for o in allops]
         for (bi, bm, br) in bufs:
             bi[...] = idx_h
@@ -400,8 +398,6 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
         t0 = time.perf_counter()
         stream_queries()
         pipelined = (time.perf_counter() - t0) / nq
-        for o in allops:
-            o.cc.set_run_streams(run_streams)
     # leave the operators as the timed region expects them: inputs resident
     op.setIndexDevice(idx.data_ptr())
     op.setMinusCompareElementDevice(minus.data_ptr())
@@ -411,7 +407,7 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
     mib = (idx_h.nbytes + minus_h.nbytes) / 2**20
     out = {}
     if pipelined is not None:
-        out = {"run_host_async_stream_ms_per_query": pipelined * 1e3, "run_host_async_slots": 2,
+        out = {"run_host_async_stream_ms_per_query": pipelined * 1e3, "run_host_async_slots": 1 + len(more_ops),
                "value_run_host_async_stream": b / pipelined}
     return {**out, "unit": "ms", "iters": iters,
             "separate_calls_ms": sep * 1e3, "separate_calls_with_results_ms": sep_res * 1e3,
