@@ -442,6 +442,9 @@ def main():
     ap.add_argument("--collective", default="auto", choices=["auto", "gather", "all_gather"],
                     help="result collection across ranks: to rank 0 (what a server needs) or to every rank; auto times both "
                          "once before the warm-up and keeps the faster")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="rehearsal of the N > 1 code path on a one-GPU box: every rank uses cuda:0 and the results are gathered "
+                         "over gloo (host-staged).  The timing means nothing; the line is marked")
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: run the RCCL gather path even with one rank (launch under torch.distributed.run)")
     args = ap.parse_args()
@@ -455,7 +458,7 @@ def main():
     from nested_hashing_psi_amd import pie, shard
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
@@ -470,7 +473,10 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
 
     cfg = dict(CONFIGS[args.config], name=args.config)
     N, L, t, K, E, b = cfg["N"], cfg["L"], cfg["t"], cfg["K"], cfg["E"], cfg["b"]
@@ -535,7 +541,7 @@ def main():
                         probe.step()
                     probe.drain()
                     torch.cuda.synchronize(device)
-                    tt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=device)
+                    tt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
                     dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
                     times[kind] = float(tt_.item())
                     del probe
@@ -582,7 +588,7 @@ def main():
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -631,10 +637,11 @@ def main():
                                    % (cname, N, L, t, cfg["S"].bit_length() - 1, cfg["C"].bit_length() - 1, cfg["k"], cfg["e"], B, K, E,
                                       b_total, b_local, b_total * K * E, b_total * (K - 1), b_total),
                        "result_ciphertexts_per_step": b_total, "parallelism": "bins%d" % world,
-                       "collective": ("rccl %s of results" % args.collective) if use_dist else "none",
+                       "collective": ("%s %s of results" % ("gloo (rehearsal)" if args.rehearse_on_one_gpu else "rccl", args.collective)) if use_dist else "none",
                        "queries_in_flight": in_flight},
             "mac_per_s": b_total * K * E / (ms_per_step * 1e-3), "mul_per_s": b_total * (K - 1) / (ms_per_step * 1e-3),
             "queries_in_flight": in_flight, "run_streams": run_streams or 2, "hipgraph": bool(args.graph),
+            **({"rehearsal": "all ranks on one GPU, gloo gather: not a measurement"} if args.rehearse_on_one_gpu else {}),
             # whole run(): algorithmic bytes of the REFERENCE's unfused schedule over the measured time.  Not HBM
             # utilisation: this build's schedule moves fewer bytes than the formula counts (fused stage A, 95 instead of 111
             # limb transforms per multiplication), so the fraction says how far the run is from the 8 TB/s bound of that schedule

@@ -33,9 +33,11 @@ for i in range(max(PS)):
     ops.append((op, idx, minus, stream))
     ccs.append(cc)
 sync = lambda: torch.cuda.synchronize(dev)
+GRAPH = os.environ.get("GRAPH", "0") == "1"
 for q in (1, 2):
     for cc in ccs:
         cc.set_run_streams(q)
+        cc.set_graph(GRAPH)
     print("queues per run %d: one query at a time %.1f us per run()" % (q, 1e3 * bench.time_runs(ops[0][0], 200, 20, sync)))
     for P in PS:
         for _ in range(10):
