@@ -55,7 +55,11 @@ __global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *__restric
         const u64x2 i1 = *reinterpret_cast<const u64x2 *>(pi + (size_t)j * 2 * LN + LN);
         u64x2 d[BPT];
 #pragma unroll
-        for (int t = 0; t < BPT; t++) d[t] = *reinterpret_cast<const u64x2 *>(pd + (size_t)t * bin_stride + (size_t)j * LN);
+        for (int t = 0; t < BPT; t++) {  // streamed once per run(): non-temporal (see stage_a_mad_kernel)
+            typedef u64 u64v2 __attribute__((ext_vector_type(2)));
+            const u64v2 v = __builtin_nontemporal_load(reinterpret_cast<const u64v2 *>(pd + (size_t)t * bin_stride + (size_t)j * LN));
+            d[t].x = v.x, d[t].y = v.y;
+        }
 #pragma unroll
         for (int t = 0; t < BPT; t++) {
             mac128(a[t][0][0], i0.x, d[t].x);
@@ -121,7 +125,10 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
         vi[0] = pij[nl];
         vi[1] = (pij + LN)[nl];
 #pragma unroll
-        for (int t = 0; t < BPT; t++) vd[t] = (pdj + (size_t)t * bin_stride)[nl];
+        // the database is read once per run() and is as large as the infinity cache: non-temporal loads keep it from evicting
+        // the (dirty) intermediate arrays the neighbouring kernels hand to each other there -- 59 -> 50 us for this kernel
+        // inside a run(), where it otherwise also paid for those write-backs (alone on the GPU it took 49 us either way)
+        for (int t = 0; t < BPT; t++) vd[t] = __builtin_nontemporal_load(pdj + (size_t)t * bin_stride + nl);
     };
     // a ring of SA_DEPTH term buffers; the term loop is unrolled SA_DEPTH times so that the ring needs no register moves
     u64 qiv[SA_DEPTH][2], qdv[SA_DEPTH][BPT];
