@@ -12,6 +12,7 @@
 // hipCUB: the only library primitive in this code base), which reproduces the reference's per-bucket item
 // order; the k*e blocked Cuckoo tables are then filled independently, one thread per table, each with its
 // own eviction generator; the bin-layer shuffle runs one thread per (table, inner hash) row.
+#include <algorithm>
 #include <hipcub/hipcub.hpp>
 
 #include "kernels.hpp"
@@ -154,6 +155,106 @@ __global__ void __launch_bounds__(64) cuckoo_build_kernel(const u64 *__restrict_
     }
 }
 
+// The same insertion walk with one WAVE per inner table and the table in LDS (K b E words: 3 KiB at the headline shape).
+// The walk is sequential in the items (the reference's insertion order decides which item is evicted), but each step is a
+// column scan: the lanes read the b cells of the item's column at once and a ballot finds the first empty one; the 16
+// table look-ups of a tabulation hash are one load per lane and an XOR reduction.  One thread per table spent 2.1 ms per
+// outer hash function at |S| = 2^20 (78 waves on 1024 SIMDs, every lane in its own table: no two loads coalesce).
+// Same generator, same draws (one per eviction), same result as cuckoo_build_kernel.
+__device__ __forceinline__ u64 wave_xor16(u64 v)  // XOR over each aligned group of 16 lanes, result in all of them
+{
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) v ^= __shfl_xor(v, d, 64);
+    return v;
+}
+__global__ void __launch_bounds__(256) cuckoo_build_wave_kernel(const u64 *__restrict__ tab, const u64 *__restrict__ items,
+                                                                const u32 *__restrict__ order, const u32 *__restrict__ start,
+                                                                u32 of, u32 k, u32 e, u32 K, u32 b, u32 E, u64 evict_seed,
+                                                                u64 *__restrict__ tbl, u32 *__restrict__ fail, u32 waves_per_block)
+{
+    extern __shared__ u64 lds_tables[];
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 p = blockIdx.x * waves_per_block + wave;
+    if (wave >= waves_per_block || p >= e) return;  // no workgroup barrier below: waves are independent
+    const u32 cells = K * b * E;
+    // per wave: the table, then the columns of the current batch of 64 items under every inner function [K][64]
+    u64 *T = lds_tables + (size_t)wave * (cells + (K * 64 + 1) / 2);
+    u32 *S = reinterpret_cast<u32 *>(T + cells);
+    for (u32 c = lane; c < cells; c += 64) T[c] = 0;
+    Rng rng;  // wave-uniform: every lane carries the same state
+    rng_seed(rng, evict_seed * 0x100000001B3ULL + (u64)of * e + p);
+    // column of an evicted item (wave-uniform x, rare): lanes 0..15 fetch the 16 table entries of the hash
+    auto column = [&](u64 x, u32 hf) -> u32 {
+        const u32 i = lane & 15;
+        const u64 part = tab[((size_t)(k + hf) * 16 + i) * 256 + (i < 8 ? (u32)((x >> (8 * i)) & 0xff) : 0u)];
+        return (u32)(wave_xor16(part) % E);
+    };
+    // first empty bin of column (hf, idx), or b if it is full; hit: some bin of the column holds x
+    auto scan = [&](u32 hf, u32 idx, u64 x, bool &hit) -> u32 {
+        u32 first = b;
+        hit = false;
+        for (u32 b0 = 0; b0 < b; b0 += 64) {
+            const u32 bin = b0 + lane;
+            const u64 cur = bin < b ? T[((size_t)hf * b + bin) * E + idx] : ~(u64)0;
+            const u64 zero = __ballot(cur == 0), same = __ballot(bin < b && cur == x);
+            hit = hit || same != 0;
+            if (zero != 0 && first == b) first = b0 + (u32)__ffsll((unsigned long long)zero) - 1;
+        }
+        return first;
+    };
+    const u32 a_end = start[p + 1];
+    bool failed = false;
+    for (u32 a0 = start[p]; a0 < a_end && !failed; a0 += 64) {
+        // this batch: lane t holds item t and hashes it under every inner function (all its table look-ups in flight at once)
+        const u64 mine = a0 + lane < a_end ? items[order[a0 + lane]] : 0;
+        for (u32 hf = 0; hf < K; hf++) S[hf * 64 + lane] = (u32)(tab_hash(tab, mine, k + hf) % E);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const u32 cnt = a_end - a0 < 64 ? a_end - a0 : 64;
+        for (u32 t = 0; t < cnt && !failed; t++) {
+            u64 x = __shfl(mine, (int)t, 64);
+            // lookUp: the item is already in one of its columns
+            bool dup = false;
+            for (u32 hf = 0; hf < K && !dup; hf++) {
+                bool hit;
+                (void)scan(hf, S[hf * 64 + t], x, hit);
+                dup = hit;
+            }
+            if (dup) continue;
+            bool placed = false, original = true;  // original: x is still item t (its columns are in S)
+            for (u32 run = 0; run < 1000 && !placed; run++) {  // numberOfRetries, CuckooHashTable.hpp:30
+                for (u32 hf = 0; hf < K && !placed; hf++) {
+                    const u32 idx = original ? S[hf * 64 + t] : column(x, hf);
+                    bool hit;
+                    const u32 first = scan(hf, idx, x, hit);
+                    if (first < b) {
+                        if (lane == 0) T[((size_t)hf * b + first) * E + idx] = x;
+                        placed = true;
+                    } else {
+                        const u32 ri = (u32)rng_below(rng, b);
+                        u64 *cell = &T[((size_t)hf * b + ri) * E + idx];
+                        const u64 tmp = *cell;  // every lane reads the same word
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == 0) *cell = x;
+                        x = tmp;
+                        original = false;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (!placed) {
+                if (lane == 0) atomicOr(fail, 1u);  // "(Blocked) Cuckoo hashing error", CuckooHashTable.cpp:113
+                failed = true;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // S is rewritten by the next batch
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    u64 *G = tbl + ((size_t)of * e + p) * cells;
+    for (u32 c = lane; c < cells; c += 64) G[c] = T[c];
+}
+
 // Fisher-Yates over the b bin layers of one (table, inner hash) row, generator seeded per row
 __global__ void __launch_bounds__(64) shuffle_rows_kernel(u64 *__restrict__ tbl, u32 rows, u32 b, u32 E, u64 seed)
 {
@@ -229,8 +330,15 @@ hipError_t launch_hash_build(const u64 *d_tab, const u64 *d_items, u32 n, u32 k,
                                                             (int)n, 0, bits, st);
         if (err != hipSuccess) return err;
         hipLaunchKernelGGL(bucket_bounds_kernel, dim3((e + 1 + HTPB - 1) / HTPB), dim3(HTPB), 0, st, keys_out, n, e, d_start);
-        hipLaunchKernelGGL(cuckoo_build_kernel, dim3((e + 63) / 64), dim3(64), 0, st, d_tab, d_items, vals_out, d_start, of, k, e, K, b,
-                           E, evict_seed, d_tbl, d_fail);
+        const size_t table_bytes = ((size_t)K * b * E + (K * 64 + 1) / 2) * sizeof(u64);  // + the batch's columns
+        if (table_bytes <= 64 * 1024) {  // one wave per table, table in LDS
+            const u32 wpb = (u32)std::max<size_t>(1, std::min<size_t>(4, (64 * 1024) / table_bytes));
+            hipLaunchKernelGGL(cuckoo_build_wave_kernel, dim3((e + wpb - 1) / wpb), dim3(64 * wpb), wpb * table_bytes, st, d_tab, d_items,
+                               vals_out, d_start, of, k, e, K, b, E, evict_seed, d_tbl, d_fail, wpb);
+        } else {
+            hipLaunchKernelGGL(cuckoo_build_kernel, dim3((e + 63) / 64), dim3(64), 0, st, d_tab, d_items, vals_out, d_start, of, k, e, K, b,
+                               E, evict_seed, d_tbl, d_fail);
+        }
     }
     const u32 rows = k * e * K;
     hipLaunchKernelGGL(shuffle_rows_kernel, dim3((rows + 63) / 64), dim3(64), 0, st, d_tbl, rows, b, E, shuffle_seed);
