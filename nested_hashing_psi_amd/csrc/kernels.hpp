@@ -163,7 +163,8 @@ void launch_mask_slots(u64 t, u32 b, u32 B, u64 seed, int64_t *d_out, hipStream_
 
 // ---- client harness (kernels_client.hip) ----------------------------------------------------------------------------
 void launch_enc_message(const DevConsts *dc, u32 N, u32 L, u32 M, const u64 *coeff_t, const int32_t *e, u64 *em, u32 nct, hipStream_t st);
-void launch_enc_finish(const DevConsts *dc, u32 N, u32 L, const u64 *em, const u64 *sk, u64 *out, u32 nct, hipStream_t st);
+void launch_enc_finish(const DevConsts *dc, u32 N, u32 L, const u64 *em, const u64 *sk, const u64 *a_in, u64 *out, u32 nct,
+                       hipStream_t st);
 void launch_ks_finish(const DevConsts *dc, u32 N, u32 L, const u64 *e, const u64 *sk, const u64 *s_from, u64 *ks, hipStream_t st);
 void launch_square(const DevConsts *dc, u32 N, u32 L, const u64 *s, u64 *s2, hipStream_t st);
 void launch_dec_dot(const DevConsts *dc, u32 N, u32 L, const u64 *ct, const u64 *sk, u64 *xs, u32 nct, hipStream_t st);

@@ -32,14 +32,17 @@ __global__ void __launch_bounds__(CTPB) enc_message_kernel(const DevConsts *__re
 
 // c0 = em - a s   (all EVALUATION); ct layout [ct][2][L][N] with c1 = a already in place
 __global__ void __launch_bounds__(CTPB) enc_finish_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, const u64 *__restrict__ em,
-                                                          const u64 *__restrict__ sk, u64 *__restrict__ out)
+                                                          const u64 *__restrict__ sk, const u64 *__restrict__ a_in,
+                                                          u64 *__restrict__ out)
 {
     const u32 n = blockIdx.x * CTPB + threadIdx.x;
     if (n >= N) return;
     const u32 l = blockIdx.y, ct = blockIdx.z;
     const Mod m = dc->mod[l];
     const size_t LN = (size_t)L * N, x = (size_t)l * N + n;
-    const u64 a = out[(size_t)ct * 2 * LN + LN + x];
+    // a_in: the uniform polynomials [nct][L][N] as uploaded; null: they already sit in the c1 halves of out
+    const u64 a = a_in ? a_in[(size_t)ct * LN + x] : out[(size_t)ct * 2 * LN + LN + x];
+    if (a_in) out[(size_t)ct * 2 * LN + LN + x] = a;
     out[(size_t)ct * 2 * LN + x] = submod(em[(size_t)ct * LN + x], mulmod(a, sk[x], m), m.q);
 }
 
@@ -119,9 +122,10 @@ void launch_enc_message(const DevConsts *dc, u32 N, u32 L, u32 M, const u64 *coe
 {
     hipLaunchKernelGGL(enc_message_kernel, dim3((N + CTPB - 1) / CTPB, L, nct), dim3(CTPB), 0, st, dc, N, L, M, coeff_t, e, em);
 }
-void launch_enc_finish(const DevConsts *dc, u32 N, u32 L, const u64 *em, const u64 *sk, u64 *out, u32 nct, hipStream_t st)
+void launch_enc_finish(const DevConsts *dc, u32 N, u32 L, const u64 *em, const u64 *sk, const u64 *a_in, u64 *out, u32 nct,
+                       hipStream_t st)
 {
-    hipLaunchKernelGGL(enc_finish_kernel, dim3((N + CTPB - 1) / CTPB, L, nct), dim3(CTPB), 0, st, dc, N, L, em, sk, out);
+    hipLaunchKernelGGL(enc_finish_kernel, dim3((N + CTPB - 1) / CTPB, L, nct), dim3(CTPB), 0, st, dc, N, L, em, sk, a_in, out);
 }
 void launch_ks_finish(const DevConsts *dc, u32 N, u32 L, const u64 *e, const u64 *sk, const u64 *s_from, u64 *ks, hipStream_t st)
 {

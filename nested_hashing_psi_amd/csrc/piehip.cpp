@@ -11,6 +11,7 @@
 #include <random>
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -2040,15 +2041,16 @@ int piehip_client_encrypt(piehip_handle h, const uint64_t *sk, const int64_t *sl
     const u64 t = h->hp.t;
     for (size_t i = 0; i < (size_t)nct * B; i++)
         if ((u64)(slots[i] < 0 ? -slots[i] : slots[i]) >= t) return fail(PIEHIP_EINVAL, "slot value out of range for the plaintext modulus");
-    std::vector<u64> cts((size_t)nct * 2 * LN);
-    std::vector<int32_t> ev((size_t)nct * N);
+    // host staging, not zero-filled (the sampling threads touch their own parts): a[nct][L][N] and e[nct][N]
+    std::unique_ptr<u64[]> a_host(new u64[(size_t)nct * LN]);
+    std::unique_ptr<int32_t[]> ev(new int32_t[(size_t)nct * N]);
     {
         // every ciphertext has its own seed and draws a (uniform), then e, as a sequential client would: the ciphertexts are
         // independent, so host threads share them out (2.4 M rejection-sampled words for the 29 ciphertexts of a C3 query)
         auto sample = [&](u32 c0, u32 c1) {
             for (u32 c = c0; c < c1; c++) {
                 HostRng r(seeds[c]);
-                sample_uniform(r, h->hp, &cts[(size_t)c * 2 * LN + LN]);
+                sample_uniform(r, h->hp, &a_host[(size_t)c * LN]);
                 sample_error(r, N, &ev[(size_t)c * N]);
             }
         };
@@ -2059,25 +2061,27 @@ int piehip_client_encrypt(piehip_handle h, const uint64_t *sk, const int64_t *sl
         sample(0, nct / nth);
         for (auto &th : pool) th.join();
     }
+    const size_t ct_words = (size_t)nct * 2 * LN;
     Tmp tmp(h);
-    TMPGET(d_out, cts.size());
+    TMPGET(d_out, ct_words);
     TMPGET(d_sk, LN);
     TMPGET(d_slotsw, (size_t)nct * B);
     TMPGET(d_u, (size_t)nct * N);
     TMPGET(d_em, (size_t)nct * LN);
     TMPGET(d_evw, ((size_t)nct * N + 1) / 2 + 1);
-    HIPCHK(hipMemcpy(d_out, cts.data(), cts.size() * sizeof(u64), hipMemcpyHostToDevice));
+    TMPGET(d_a, (size_t)nct * LN);
+    HIPCHK(hipMemcpy(d_a, a_host.get(), (size_t)nct * LN * sizeof(u64), hipMemcpyHostToDevice));  // enc_finish puts it into the c1 halves
     HIPCHK(hipMemcpy(d_sk, sk, LN * sizeof(u64), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_slotsw, slots, sizeof(int64_t) * (size_t)nct * B, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_evw, ev.data(), sizeof(int32_t) * ev.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_evw, ev.get(), sizeof(int32_t) * (size_t)nct * N, hipMemcpyHostToDevice));
     launch_encode_scatter(h->d_dc, N, M, (const int64_t *)d_slotsw, B, h->d_inv_pos, d_u, nct, h->stream);
     launch_ntt(h->plan, d_u, nct, M, 1, true, h->stream);  // coefficients mod t
     launch_enc_message(h->d_dc, N, L, M, d_u, (const int32_t *)d_evw, d_em, nct, h->stream);
     launch_ntt(h->plan, d_em, nct * L, 0, L, false, h->stream);
-    launch_enc_finish(h->d_dc, N, L, d_em, d_sk, d_out, nct, h->stream);
+    launch_enc_finish(h->d_dc, N, L, d_em, d_sk, d_a, d_out, nct, h->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(out, d_out, cts.size() * sizeof(u64), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, d_out, ct_words * sizeof(u64), hipMemcpyDeviceToHost));
     return PIEHIP_OK;
 }
 
