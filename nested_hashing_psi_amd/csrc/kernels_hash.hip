@@ -10,8 +10,9 @@
 //
 // Structure: per outer hash function, items are keyed by their bucket and stably radix-sorted (rocPRIM via
 // hipCUB: the only library primitive in this code base), which reproduces the reference's per-bucket item
-// order; the k*e blocked Cuckoo tables are then filled independently, one thread per table, each with its
-// own eviction generator; the bin-layer shuffle runs one thread per (table, inner hash) row.
+// order; the k*e blocked Cuckoo tables are then filled independently, one wave per table with the table in LDS
+// (one thread per table when a table does not fit), each with its own eviction generator; the bin-layer shuffle runs
+// one thread per (table, inner hash) row.
 #include <algorithm>
 #include <hipcub/hipcub.hpp>
 
