@@ -259,6 +259,8 @@ def test_several_handles_and_sharded_facade_in_one_process(tmp_path):
     (2048, 3, T32, 5000, 3, 100, 2, 10, 6),
     (16384, 4, T32, 1 << 17, 2, 1000, 2, 14, 8),
     (1024, 2, T16, 40, 2, 3, 3, 5, 2),
+    (1024, 2, T16, 600, 2, 4, 2, 4, 70),       # more bin layers than lanes: the column scan takes two steps
+    (1024, 2, T16, 3000, 2, 2, 3, 50, 60),     # 72 KiB per inner table: the one-thread-per-table kernel
 ])
 def test_offline_phase_on_device(ob, pie, N, L, t, nS, k, e, K, E, b):
     """piehip_build_db == oracle ph_hct_build + ph_hct_shuffle_bins + ph_pack_db + ph_masks + encode, bit for bit:
