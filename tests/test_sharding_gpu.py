@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, backend, b, nq, q):
+def _worker(rank, world, port, backend, b, nq, q, nslots=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -55,42 +55,50 @@ def _worker(rank, world, port, backend, b, nq, q):
         if hi > lo:
             op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=np.ascontiguousarray(db[:, lo:hi]), preCalcRandomMask=np.ascontiguousarray(masks[lo:hi]))
         ct_words = 2 * L * N
-        d_idx = torch.zeros((K, E, 2, L, N), dtype=torch.int64, device=device)
-        d_minus = torch.zeros((2, L, N), dtype=torch.int64, device=device)
-        rg = shard.ResultGather(op, b, hi - lo, ct_words, device, stream, kind="gather")
+        # query slots (bench.py's N > 1 path): every slot has its own context, stream, inputs and double-buffered gather; the
+        # queries go round the slots, so the slots' collectives interleave in the same order on every rank
+        slots = []
+        for s_ in range(nslots):
+            st_ = stream if s_ == 0 else torch.cuda.Stream(device)
+            cc_ = cc if s_ == 0 else pie.PieContext(N, L, t, device=0, stream=st_.cuda_stream)
+            op_ = op if s_ == 0 else (pie.BatchedFHEHIPPIE(cc_, attachTo=op) if op is not None else None)
+            slots.append(dict(cc=cc_, op=op_, stream=st_,
+                              d_idx=torch.zeros((K, E, 2, L, N), dtype=torch.int64, device=device),
+                              d_minus=torch.zeros((2, L, N), dtype=torch.int64, device=device),
+                              rg=shard.ResultGather(op_, b, hi - lo, ct_words, device, st_, kind="gather")))
         got = []
         for i, (idx, minus) in enumerate(queries):
-            with torch.cuda.stream(stream):   # the next query overwrites the input arrays in stream order
-                d_idx.copy_(torch.from_numpy(idx.view(np.int64)), non_blocking=False)
-                d_minus.copy_(torch.from_numpy(minus.view(np.int64)), non_blocking=False)
-            if op is not None:
-                op.setIndexDevice(d_idx.data_ptr())
-                op.setMinusCompareElementDevice(d_minus.data_ptr())
-            s = rg.step()
-            if i >= 1:   # query i-1 has been gathered by now or will be by the drain below; collect lazily
-                pass
-            got.append(s)
-        rg.drain()
+            sl = slots[i % nslots]
+            with torch.cuda.stream(sl["stream"]):   # the slot's next query overwrites its input arrays in stream order
+                sl["d_idx"].copy_(torch.from_numpy(idx.view(np.int64)), non_blocking=False)
+                sl["d_minus"].copy_(torch.from_numpy(minus.view(np.int64)), non_blocking=False)
+            if sl["op"] is not None:
+                sl["op"].setIndexDevice(sl["d_idx"].data_ptr())
+                sl["op"].setMinusCompareElementDevice(sl["d_minus"].data_ptr())
+            got.append((sl, sl["rg"].step()))
+        for sl in slots:
+            sl["rg"].drain()
         torch.cuda.synchronize(device)
         ok = True
         detail = ""
         if rank == 0:
-            # the last two queries are still in the two buffer sets: compare them with an unsharded handle
+            # the last two queries of every slot are still in its two buffer sets: compare them with an unsharded handle
             cc1 = pie.PieContext(N, L, t, device=0)
             cc1.load_relin_key(evk)
             full = pie.BatchedFHEHIPPIE(cc1, vectorizedHCT=db, preCalcRandomMask=masks)
-            for i in (nq - 2, nq - 1):
+            for i in range(max(0, nq - 2 * nslots), nq):
                 idx, minus = queries[i]
                 full.setMinusCompareElement(minus)
                 full.setIndex(idx)
                 full.run()
                 want = full.getResultList().reshape(b, ct_words).view(np.int64)
-                rows = rg.rows(got[i]).cpu().numpy()
+                rows = got[i][0]["rg"].rows(got[i][1]).cpu().numpy()
                 if rows.shape != want.shape or not (rows == want).all():
                     ok = False
                     detail += "query %d differs; " % i
             cc1.close()
-        cc.close()
+        for sl in reversed(slots):
+            sl["cc"].close()
         q.put((rank, ok, detail))
     except Exception as e:  # report instead of hanging the parent on q.get
         import traceback
@@ -102,12 +110,12 @@ def _worker(rank, world, port, backend, b, nq, q):
             pass
 
 
-def _run(world, backend, b, nq=5):
+def _run(world, backend, b, nq=5, nslots=1):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, b, nq, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, b, nq, q, nslots)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(world)]
@@ -122,6 +130,13 @@ def test_sharded_ranks_on_one_gpu_match_unsharded(world, b):
     _run(world, "gloo", b)
 
 
+def test_sharded_ranks_with_query_slots():
+    """two ranks x three query slots each (bench.py's N > 1 configuration): nine different queries go round the slots, every
+    slot double-buffers its own gather, and the last two queries of every slot equal the unsharded evaluation"""
+    _run(2, "gloo", 7, nq=9, nslots=3)
+
+
 def test_one_rank_rccl_device_gather():
-    """the RCCL form of the same sequence (device tensors, asynchronous gather on RCCL's stream)"""
+    """the RCCL form of the same sequence (device tensors, asynchronous gather on RCCL's stream), also over three slots"""
     _run(1, "nccl", 6)
+    _run(1, "nccl", 6, nq=7, nslots=3)
