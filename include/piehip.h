@@ -129,7 +129,9 @@ int piehip_set_index_device(piehip_handle h, const void *d_idx);
 int piehip_set_minus_device(piehip_handle h, const void *d_minus);
 
 /* run() (BatchedFHEHIPPIE.cpp:88-129): enqueue the whole evaluation on the handle's stream.
- * Asynchronous; piehip_sync() or piehip_get_results() waits for it. */
+ * Asynchronous; piehip_sync() or piehip_get_results() waits for it.
+ * K = 1 (a database loaded with piehip_load_db / _slots; the hashing entry points refuse it as CuckooHashTable.cpp:39-42 does):
+ * multipliedResult is the inner product itself (.cpp:117-120), so run() is stage A and the mask multiply (.cpp:126); no key needed. */
 int piehip_run(piehip_handle h);
 /* the same, with the result ciphertexts written straight into caller-owned HBM d_results[b][2][L][N] (e.g. the RCCL
  * gather buffer) instead of the handle's result buffer */
@@ -151,6 +153,18 @@ int piehip_run_host_async(piehip_handle h, const uint64_t *idx, const uint64_t *
 int piehip_run_host_wait(piehip_handle h);
 /* page-locked staging arrays owned by the handle (valid until the database shape changes or the handle is destroyed) */
 int piehip_host_buffers(piehip_handle h, uint64_t **idx, uint64_t **minus, uint64_t **results);
+/* piehip_run_host_async piece by piece, for a server that receives the query message by message -- one message per ciphertext,
+ * the minus element first (BatchedFHEPSIServer.cpp:94-95,114-141): every piece starts its upload as soon as the deserialiser has
+ * written it (into the page-locked arrays above, or any host memory that stays valid until piehip_run_host_wait), so the 29 MiB of
+ * a C3 query cross PCIe while the remaining messages are still arriving, i.e. before the reference's timer starts (.cpp:98-99).
+ *   piehip_stage_minus      the minus element [2][L][N]
+ *   piehip_stage_index_row  row `row` (one inner hash function) of the index matrix, [E][2][L][N]
+ *   piehip_run_staged       setMinusCompareElement + setIndex + run + getResultList on the staged pieces: stage A of row h waits
+ *                           for that row only; results (may be NULL) are complete after piehip_run_host_wait.
+ * PIEHIP_ESTATE when a piece is missing.  piehip_run_host_async is exactly: stage_minus, stage_index_row for every row, run_staged. */
+int piehip_stage_minus(piehip_handle h, const uint64_t *minus);
+int piehip_stage_index_row(piehip_handle h, uint32_t row, const uint64_t *row_data);
+int piehip_run_staged(piehip_handle h, uint64_t *results);
 /* Stream order.  run() works on the handle's own queues (piehip_set_run_streams); it waits for the handle's stream
  * where it must (new inputs; the result buffer), and the handle's stream waits for the run in the next call of any
  * other entry point -- piehip_join() does only that, piehip_sync() also blocks the host.  Work queued on the handle's
@@ -170,10 +184,10 @@ int piehip_set_graph(piehip_handle h, int on);
  * database and masks by reference -- nothing is copied -- and gets a run() workspace of its own, so that queries set and
  * run on the two handles (each on its own stream) overlap: one query's plaintext-ciphertext stage is HBM-bound while the
  * other's transforms are ALU-bound.  The reference operator evaluates one query at a time (BatchedFHEHIPPIE.cpp:88-129);
- * this is how a server with several clients keeps the GPU full.  While handles are attached, `owner` refuses to be
- * destroyed or to load a database of another shape (PIEHIP_ESTATE); reloading a key or a same-shape database into it
- * rewrites the shared buffers in place, so do that only between queries.  Loading a database into `h` itself returns it to a
- * private copy (load_relin_key is refused while attached). */
+ * this is how a server with several clients keeps the GPU full.  While handles are attached, `owner` refuses (PIEHIP_ESTATE)
+ * to be destroyed, to load or build a database of any shape, to reload its key and to attach itself elsewhere: the attached
+ * handles read those buffers on streams of their own.  Loading a database into `h` itself returns it to a private copy
+ * (load_relin_key is refused while attached). */
 int piehip_attach_database(piehip_handle h, piehip_handle owner);
 /* getResultList (BatchedFHEHIPPIE.hpp:35-38): out[b][2][L][N] */
 int piehip_get_results(piehip_handle h, uint64_t *out);

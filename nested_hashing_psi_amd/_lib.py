@@ -47,6 +47,9 @@ SYMBOLS = {
     "piehip_run_host": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "piehip_run_host_async": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "piehip_run_host_wait": (C.c_int, [C.c_void_p]),
+    "piehip_stage_minus": (C.c_int, [C.c_void_p, u64p]),
+    "piehip_stage_index_row": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
+    "piehip_run_staged": (C.c_int, [C.c_void_p, u64p]),
     "piehip_host_buffers": (C.c_int, [C.c_void_p, C.POINTER(u64p), C.POINTER(u64p), C.POINTER(u64p)]),
     "piehip_set_run_streams": (C.c_int, [C.c_void_p, C.c_uint32]),
     "piehip_set_graph": (C.c_int, [C.c_void_p, C.c_int]),

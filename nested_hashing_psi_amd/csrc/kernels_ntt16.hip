@@ -42,8 +42,6 @@ bool launch_ntt16(const NttPlan &pl, bool folded, u64 *data, u32 nlimbs, u32 mod
     a.copy_K = ex ? ex->copy_K : 1;
     a.copy_L = ex ? ex->copy_L : 1;
     a.copy_M = ex ? ex->copy_M : 1;
-    a.stagger_from = ~0u;
-    a.stagger_sleeps = 0;
     a.lift_first = ~0u;
     a.data2 = nullptr;
     a.lift_src = nullptr;

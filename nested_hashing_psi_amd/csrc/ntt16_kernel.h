@@ -104,6 +104,19 @@ __device__ __forceinline__ void bfly2(u64 &x0, u64 &y0, const Tw &t0, u64 &x1, u
 // m-th index in [0, 16) whose bit `d` (a power of two) is clear
 __device__ __forceinline__ constexpr int bfly_lo(int m, int d) { return ((m & ~(d - 1)) << 1) | (m & (d - 1)); }
 
+// Wave-uniform tables (twiddles of passes 1 and 2, modulus constants) are read through the constant address space: a
+// plain global pointer gives vector loads of a uniform address (the compiler cannot prove that the kernel's own stores leave
+// the tables alone) -- 22 global_load_dwordx4 per slice queued in order behind the slice's HBM loads, four VGPRs per
+// twiddle, VGPR operands in the butterfly blocks.  Through address space 4 they are s_load_dwordx4 into SGPRs.
+typedef const __attribute__((address_space(4))) u64x2 *TwS;
+typedef const __attribute__((address_space(4))) DevConsts *DcS;
+__device__ __forceinline__ u64 uniform_addr(const void *p)  // (uniform integer divisions leave their results in VGPRs)
+{
+    const u64 v = (u64)p;
+    const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
 // DS operations of one wave execute in issue order: a hand-off inside the wave only needs the compiler kept from
 // moving the reads above the writes
 __device__ __forceinline__ void wave_sync()
@@ -128,8 +141,6 @@ struct Args {
     // copy_out[bin][4][copy_M][N], slots 0, 1, limbs < copy_L (input limbs are [nb][copy_K][2][copy_L])
     u64 *copy_out;
     u32 copy_K, copy_L, copy_M;
-    // workgroups from this index on begin stagger_sleeps x ~1000 cycles late (see the kernel); stagger_from >= grid: off
-    u32 stagger_from, stagger_sleeps;
     // forward: items [lift_first, nitems) are BV key-switch digits: limb (bin, i, j) of data2[nb][lift_L][lift_L][N]
     // is the centred lift into q_j of residue limb i of the COEFFICIENT polynomial lift_src + bin * lift_stride, transformed;
     // the lift (and, with two folded slices per limb, the outermost stage) happens in the load phase.  lift_first >= nitems: off
@@ -225,26 +236,19 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
         }
         return lb;
     };
-    // Workgroups that share a CU with an earlier one start a little late: every workgroup of a launch begins with 64 KiB of
-    // loads, and issued together the two streams of a CU interleave and complete together -- a phase in which the whole chip
-    // waits for HBM and no ALU has work, followed by one in which HBM idles.  Behind a ~1 us head start the first stream is
-    // served first, its workgroup computes while the second one loads, and the stores at the end stagger the same way.
-    if (blockIdx.x >= a.stagger_from) {
-        for (u32 i = 0; i < a.stagger_sleeps; i++) __builtin_amdgcn_s_sleep(16);
-    }
-
     for (u32 item = blockIdx.x; item < a.nitems; item += gridDim.x) {
         const bool lift = LIFT && !INV && item >= a.lift_first;
         const u32 item_l = lift ? item - a.lift_first : item;
         const u32 blk = item_l & ((1u << a.s0) - 1);
         const u32 limb = lift ? item_l >> a.s0 : limb_of(item);
         u64 *const g = (lift ? a.data2 : a.data) + (((size_t)limb << a.s0) + blk) * NS;  // uniform
-        const u32 mod = a.mod_base + limb % a.mod_count;
-        const u64 q = a.dc->mod[mod].q;
+        const u32 mod = __builtin_amdgcn_readfirstlane(a.mod_base + limb % a.mod_count);
+        const DcS dcs = (DcS)uniform_addr(a.dc);
+        const u64 q = dcs->mod[mod].q;
         const u64 q2 = 2 * q, q4 = 4 * q;
         ModC mc;
         mc.nql = (u32)(0 - q), mc.nqh = (u32)((0 - q) >> 32), mc.nq4 = 0 - q4, mc.q4p1 = q4 + 1;
-        const u64x2 *__restrict__ tw = a.twp + ((size_t)mod * 2 + (INV ? 1 : 0)) * a.N;
+        const TwS tw = (TwS)uniform_addr(a.twp + ((size_t)mod * 2 + (INV ? 1 : 0)) * a.N);
         const u64x2 *__restrict__ twk = a.twk + (((size_t)mod * 2 + (INV ? 1 : 0)) << a.s0) * TWK_PER_SLICE + (size_t)blk * TWK_PER_SLICE;
         const u64x2 *__restrict__ tw3 = twk + (size_t)w * 15 * 16;                 // [slot 0..14][16 a]
         const u64x2 *__restrict__ tw4 = twk + 8 * 15 * 16 + (size_t)w * 12 * 64;   // [slot 0..11][64 l]
@@ -264,9 +268,9 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
             if (lift) {
                 // equal-width primes (q_i < 2 q_j for every pair: the host checks): a conditional subtraction reduces a residue
                 // mod q_i into q_j, and residues above q_i / 2 are corrected by q_i mod q_j (centred lift, kernels_pie.hip)
-                const u32 LL = a.lift_L, li = (limb / LL) % LL, lj = limb % LL;
+                const u32 LL = a.lift_L, li = __builtin_amdgcn_readfirstlane((limb / LL) % LL), lj = __builtin_amdgcn_readfirstlane(limb % LL);
                 const u64 *src = a.lift_src + (size_t)(limb / (LL * LL)) * a.lift_stride + (size_t)li * a.N;
-                const u64 qh = a.dc->mod[li].q / 2, qq = a.dc->qi_modqj[li][lj];
+                const u64 qh = dcs->mod[li].q / 2, qq = dcs->qi_modqj[li][lj];
                 auto lift1 = [&](u64 v) -> u64 {
                     u64 r = v >= q ? v - q : v;
                     const u64 c = v > qh ? qq : 0;
@@ -277,8 +281,8 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
                     // two folded slices per limb: the outermost stage (u, v) -> (u + v psi^{N/2}, u - v psi^{N/2}) is one more
                     // butterfly, and this slice keeps its half (kernels_pie.hip fold_store does the same for the other kernels)
                     u64x2 fw;
-                    fw.x = a.dc->fold_w[lj];
-                    fw.y = a.dc->fold_w_sh[lj] >> 1;
+                    fw.x = dcs->fold_w[lj];
+                    fw.y = dcs->fold_w_sh[lj] >> 1;
                     const Tw t = make_tw(fw);
 #pragma unroll
                     for (int r = 0; r < 8; r++) {
@@ -560,7 +564,7 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
                     bfly2<true, true>(x[2 * r], x[2 * (r + d)], t, x[2 * r + 1], x[2 * (r + d) + 1], t, mc);
                 }
             }
-            const Mod &m = a.dc->mod[mod];
+            const u64 n_inv = dcs->mod[mod].n_inv, n_inv_sh = dcs->mod[mod].n_inv_sh;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 u64x2 v;
@@ -568,8 +572,8 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
                     v.x = x[2 * r];
                     v.y = x[2 * r + 1];
                 } else if (a.s0 == 0) {
-                    v.x = mul_shoup(x[2 * r], m.n_inv, m.n_inv_sh, q);
-                    v.y = mul_shoup(x[2 * r + 1], m.n_inv, m.n_inv_sh, q);
+                    v.x = mul_shoup(x[2 * r], n_inv, n_inv_sh, q);
+                    v.y = mul_shoup(x[2 * r + 1], n_inv, n_inv_sh, q);
                 } else {  // split transform: the global-memory stages expect canonical residues
                     u64 r0 = x[2 * r], r1 = x[2 * r + 1];
                     r0 = r0 >= q2 ? r0 - q2 : r0;

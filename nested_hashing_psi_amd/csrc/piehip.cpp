@@ -89,7 +89,9 @@ struct piehip_ctx {
     // piehip_run_host: copy queue, one "row landed" event per inner hash function, pinned staging owned by the handle
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> ev_h2d;               // [K]: index-matrix row h (and, for h = 0, the minus element) is in HBM
-    hipEvent_t ev_copy_gate = nullptr;
+    hipEvent_t ev_copy_gate = nullptr, ev_minus_h2d = nullptr;
+    bool stage_open = false, staged_minus = false;  // piehip_stage_*: a query's uploads have begun; which pieces are on their way
+    std::vector<bool> staged_rows;
     const hipEvent_t *row_events = nullptr;       // set while piehip_run_host enqueues: stage A of row h waits for row_events[h]
     u64 *pin_idx = nullptr, *pin_minus = nullptr, *pin_res = nullptr;
     size_t pin_idx_words = 0, pin_res_words = 0;
@@ -602,6 +604,7 @@ int piehip_destroy(piehip_handle h)
     }
     for (hipEvent_t e : h->ev_h2d) (void)hipEventDestroy(e);
     if (h->ev_copy_gate) (void)hipEventDestroy(h->ev_copy_gate);
+    if (h->ev_minus_h2d) (void)hipEventDestroy(h->ev_minus_h2d);
     if (h->pin_idx) (void)hipHostFree(h->pin_idx);
     if (h->pin_minus) (void)hipHostFree(h->pin_minus);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
@@ -645,6 +648,7 @@ int piehip_load_relin_key(piehip_handle h, const uint64_t *evk)
     NEED(h);
     if (!evk) return fail(PIEHIP_EINVAL, "null evk");
     if (h->db_borrowed) return fail(PIEHIP_EINVAL, "this handle uses another handle's key and database (piehip_attach_database)");
+    if (h->db_borrowers) return fail(PIEHIP_ESTATE, "the key cannot be reloaded while other handles are attached to this one");
     HIPCHK(hipSetDevice(h->device));
     const size_t words = (size_t)h->hp.L * 2 * h->LN();
     if (!h->d_evk) {
@@ -686,8 +690,12 @@ static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E, bool with_db = 
         detach_database(h);
         h->K = h->b = h->E = 0;
     }
-    if (K < 2) return fail(PIEHIP_EINVAL, "Cuckoo Table needs more than one hash function!");  // CuckooHashTable.cpp:39-42
+    if (K < 1) return fail(PIEHIP_EINVAL, "at least one inner hash function");
     if (b < 1 || E < 1) return fail(PIEHIP_EINVAL, "Bin size needs to be at least of size one!");
+    // the database and masks are shared with the attached query slots, whose streams are not ordered against this handle's:
+    // rewriting them in place (same shape) would race with their runs, reallocating them would leave them dangling
+    if (with_db && h->db_borrowers)
+        return fail(PIEHIP_ESTATE, "a database cannot be loaded while other handles are attached to this one (destroy or re-home them first)");
     const size_t LN = h->LN();
     if (with_db && h->K == K && h->b == b && h->E == E && h->d_db && h->d_masks && h->d_acc && h->d_out && h->ws.nb == b) {
         // same shape as the database being replaced (or reserved): keep the 0.5 GiB of buffers (hipFree + hipMalloc cost
@@ -695,7 +703,6 @@ static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E, bool with_db = 
         h->d_idx = nullptr;
         return PIEHIP_OK;
     }
-    if (h->db_borrowers) return fail(PIEHIP_ESTATE, "a database of another shape cannot be loaded while other handles are attached to this one");
     dev_free(&h->d_db);
     dev_free(&h->d_masks);
     dev_free(&h->d_masks_sigma);
@@ -715,6 +722,7 @@ static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E, bool with_db = 
     h->b = b;
     h->E = E;
     // inputs depend on K,E: drop stale copies
+    h->stage_open = false;
     dev_free(&h->d_idx_own);
     h->d_idx = nullptr;
     return PIEHIP_OK;
@@ -743,9 +751,11 @@ int piehip_attach_database(piehip_handle h, piehip_handle owner)
 {
     NEED(h);
     if (!owner || owner == h) return fail(PIEHIP_EINVAL, "attach_database: needs another handle");
+    if (h->db_borrowers)  // its key and database are in use by the handles attached to it: nothing of them may be freed
+        return fail(PIEHIP_ESTATE, "attach_database: other handles are attached to this handle's database (detach or destroy them first)");
     join_pending(owner);
     if (owner->db_borrowed) return fail(PIEHIP_EINVAL, "attach_database: the owner itself borrows its database");
-    if (!owner->d_db || !owner->d_evk) return fail(PIEHIP_ESTATE, "attach_database: the owner has no key or no database yet");
+    if (!owner->d_db || (!owner->d_evk && owner->K > 1)) return fail(PIEHIP_ESTATE, "attach_database: the owner has no key or no database yet");
     if (owner->device != h->device) return fail(PIEHIP_EINVAL, "attach_database: handles on different devices");
     if (owner->hp.N != h->hp.N || owner->hp.L != h->hp.L || owner->hp.t != h->hp.t || owner->hp.moduli != h->hp.moduli)
         return fail(PIEHIP_EINVAL, "attach_database: handles with different parameters");
@@ -926,6 +936,7 @@ int piehip_reserve(piehip_handle h, size_t n, uint32_t k, uint32_t e, uint32_t K
 {
     NEED(h);
     if (k < 1 || e < 1 || bin_lo >= bin_hi || bin_hi > b || !n || n > 0x7FFFFFFFu) return fail(PIEHIP_EINVAL, "bad shape");
+    if (K < 2) return fail(PIEHIP_EINVAL, "Cuckoo Table needs more than one hash function!");  // CuckooHashTable.cpp:39-42
     HIPCHK(hipSetDevice(h->device));
     int rc = alloc_run_buffers(h, K, bin_hi - bin_lo, E);
     if (rc) return rc;
@@ -951,6 +962,7 @@ int piehip_build_db_bins(piehip_handle h, const uint64_t *items, size_t n, uint3
     NEED(h);
     if (!items || !n || n > 0x7FFFFFFFu) return fail(PIEHIP_EINVAL, "empty or oversized server set");
     if (k < 1 || e < 1) return fail(PIEHIP_EINVAL, "need at least one outer hash function and position");
+    if (K < 2) return fail(PIEHIP_EINVAL, "Cuckoo Table needs more than one hash function!");  // CuckooHashTable.cpp:39-42
     if (bin_lo >= bin_hi || bin_hi > b) return fail(PIEHIP_EINVAL, "bin-layer slice must be non-empty and within [0, b)");
     const size_t B = (size_t)k * e;
     if (B > h->hp.N) return fail(PIEHIP_EINVAL, "batch size k*e exceeds the ring dimension");
@@ -1006,6 +1018,7 @@ int piehip_load_db_table_bins(piehip_handle h, const uint64_t *tbl, uint32_t k, 
 {
     NEED(h);
     if (!tbl || k < 1 || e < 1) return fail(PIEHIP_EINVAL, "bad hash table");
+    if (K < 2) return fail(PIEHIP_EINVAL, "Cuckoo Table needs more than one hash function!");  // CuckooHashTable.cpp:39-42
     if (bin_lo >= bin_hi || bin_hi > b) return fail(PIEHIP_EINVAL, "bin-layer slice must be non-empty and within [0, b)");
     const size_t B = (size_t)k * e;
     if (B > h->hp.N) return fail(PIEHIP_EINVAL, "batch size k*e exceeds the ring dimension");
@@ -1161,8 +1174,16 @@ static void enqueue_run_bins(piehip_ctx *h, u32 b0, u32 nb, u64 *results)
             launch_stage_a(h->d_dc, N, L, K, nb, E, h->d_idx, h->d_minus, h->d_db + (size_t)b0 * E * LN, acc, h->stream, h->small_moduli, b);
         }
     }
+    if (K == 1) {
+        // one inner hash function: multipliedResult is the inner product itself (BatchedFHEHIPPIE.cpp:117-120), so run() is
+        // stage A and the mask multiply (:126) -- no ciphertext product, no transform, no key
+        if (h->wait_before_results) (void)hipStreamWaitEvent(h->stream, h->wait_before_results, 0);
+        ProfScope ps(h, PIEHIP_K_MASK, W * nb * 5.0 * L);
+        launch_ct_mul_plain(h->d_dc, N, L, acc, h->d_masks + (size_t)b0 * LN, LN, out, nb, h->stream);
+        return;
+    }
     // every accumulator enters a ct x ct product exactly once: switch them all to COEFFICIENT format
-    const bool xq = xq_reuse(h) && K > 1;
+    const bool xq = xq_reuse(h);
     NttExtra ex;
     ex.copy_out = w.eqp;
     ex.copy_K = K;
@@ -1191,9 +1212,8 @@ int piehip_run_into(piehip_handle h, void *d_results)
     if (!h) return fail(PIEHIP_EINVAL, "null handle");
     if (!d_results) return fail(PIEHIP_EINVAL, "null result buffer");
     if (!h->K || !h->d_db) return fail(PIEHIP_ESTATE, "run: database not loaded");
-    if (!h->d_evk) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
+    if (!h->d_evk && h->K > 1) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
     if (!h->d_idx || !h->d_minus) return fail(PIEHIP_ESTATE, "run: setIndex / setMinusCompareElement not called");
-    if (h->K < 2) return fail(PIEHIP_EINVAL, "run: at least two inner hash functions");
     HIPCHK(hipSetDevice(h->device));
     const u32 b = h->b;
     h->recs.clear();
@@ -1303,6 +1323,7 @@ static int host_path_setup(piehip_ctx *h)
 {
     if (!h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     if (!h->ev_copy_gate) HIPCHK(hipEventCreateWithFlags(&h->ev_copy_gate, hipEventDisableTiming));
+    if (!h->ev_minus_h2d) HIPCHK(hipEventCreateWithFlags(&h->ev_minus_h2d, hipEventDisableTiming));
     while (h->ev_h2d.size() < h->K) {
         hipEvent_t e = nullptr;
         HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1336,32 +1357,72 @@ int piehip_host_buffers(piehip_handle h, uint64_t **idx, uint64_t **minus, uint6
     return PIEHIP_OK;
 }
 
-int piehip_run_host_async(piehip_handle h, const uint64_t *idx, const uint64_t *minus, uint64_t *results)
+// One query's uploads, piece by piece (piehip_stage_*): the copy queue is gated once behind everything queued so far -- the uploads
+// may not overtake a run that still reads the input buffers -- and every piece is one asynchronous copy from host memory.
+static int stage_begin(piehip_ctx *h)
 {
-    if (!h) return fail(PIEHIP_EINVAL, "null handle");
-    if (!idx || !minus) return fail(PIEHIP_EINVAL, "null input");
     if (!h->K || !h->d_db) return fail(PIEHIP_ESTATE, "run: database not loaded");
-    if (!h->d_evk) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
     HIPCHK(hipSetDevice(h->device));
+    if (h->stage_open) return PIEHIP_OK;
     int rc = host_path_setup(h);
     if (rc) return rc;
     const size_t LN = h->LN(), row = (size_t)h->E * 2 * LN;
     if (!h->d_idx_own && (rc = dev_alloc(&h->d_idx_own, (size_t)h->K * row))) return rc;
     if (!h->d_minus_own && (rc = dev_alloc(&h->d_minus_own, 2 * LN))) return rc;
-    // the uploads may not overtake a run that still reads the input buffers: gate the copy queue behind everything queued so far
     join_pending(h);
     HIPCHK(hipEventRecord(h->ev_copy_gate, h->stream));
     HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_copy_gate, 0));
-    HIPCHK(hipMemcpyAsync(h->d_minus_own, minus, 2 * LN * sizeof(u64), hipMemcpyHostToDevice, h->copy_stream));
-    for (u32 hf = 0; hf < h->K; hf++) {
-        HIPCHK(hipMemcpyAsync(h->d_idx_own + (size_t)hf * row, idx + (size_t)hf * row, row * sizeof(u64), hipMemcpyHostToDevice, h->copy_stream));
-        HIPCHK(hipEventRecord(h->ev_h2d[hf], h->copy_stream));
-    }
+    h->stage_open = true;
+    h->staged_minus = false;
+    h->staged_rows.assign(h->K, false);
+    return PIEHIP_OK;
+}
+
+int piehip_stage_minus(piehip_handle h, const uint64_t *minus)
+{
+    if (!h) return fail(PIEHIP_EINVAL, "null handle");
+    if (!minus) return fail(PIEHIP_EINVAL, "null input");
+    int rc = stage_begin(h);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_minus_own, minus, 2 * h->LN() * sizeof(u64), hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(hipEventRecord(h->ev_minus_h2d, h->copy_stream));
+    h->staged_minus = true;
+    return PIEHIP_OK;
+}
+
+int piehip_stage_index_row(piehip_handle h, uint32_t row, const uint64_t *row_data)
+{
+    if (!h) return fail(PIEHIP_EINVAL, "null handle");
+    if (!row_data) return fail(PIEHIP_EINVAL, "null input");
+    int rc = stage_begin(h);
+    if (rc) return rc;
+    if (row >= h->K) return fail(PIEHIP_EINVAL, "stage_index_row: the index matrix has one row per inner hash function");
+    const size_t words = (size_t)h->E * 2 * h->LN();
+    HIPCHK(hipMemcpyAsync(h->d_idx_own + (size_t)row * words, row_data, words * sizeof(u64), hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(hipEventRecord(h->ev_h2d[row], h->copy_stream));
+    h->staged_rows[row] = true;
+    return PIEHIP_OK;
+}
+
+int piehip_run_staged(piehip_handle h, uint64_t *results)
+{
+    if (!h) return fail(PIEHIP_EINVAL, "null handle");
+    if (!h->K || !h->d_db) return fail(PIEHIP_ESTATE, "run: database not loaded");
+    if (!h->d_evk && h->K > 1) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
+    if (!h->stage_open || !h->staged_minus) return fail(PIEHIP_ESTATE, "run_staged: minus element not staged");
+    for (u32 hf = 0; hf < h->K; hf++)
+        if (!h->staged_rows[hf]) return fail(PIEHIP_ESTATE, "run_staged: index matrix row not staged");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t LN = h->LN();
+    h->stage_open = false;
     h->d_idx = h->d_idx_own;
     h->d_minus = h->d_minus_own;
+    // the minus element enters at the end of every stage A launch: the handle's stream (and, through the fork, every queue)
+    // waits for it; row h of the index matrix is waited for by stage A of row h only
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_minus_h2d, 0));
     mark_dirty(h);
     h->row_events = h->ev_h2d.data();
-    rc = piehip_run_into(h, h->d_out);
+    int rc = piehip_run_into(h, h->d_out);
     h->row_events = nullptr;
     if (rc) return rc;
     if (results) {
@@ -1383,6 +1444,22 @@ int piehip_run_host_async(piehip_handle h, const uint64_t *idx, const uint64_t *
         }
     }
     return PIEHIP_OK;
+}
+
+int piehip_run_host_async(piehip_handle h, const uint64_t *idx, const uint64_t *minus, uint64_t *results)
+{
+    if (!h) return fail(PIEHIP_EINVAL, "null handle");
+    if (!idx || !minus) return fail(PIEHIP_EINVAL, "null input");
+    if (h->K && !h->d_evk && h->K > 1) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
+    h->stage_open = false;  // a query of its own: pieces staged earlier and never run are dropped
+    int rc = piehip_stage_minus(h, minus);
+    const size_t row = (size_t)h->E * 2 * h->LN();
+    for (u32 hf = 0; hf < h->K && !rc; hf++) rc = piehip_stage_index_row(h, hf, idx + (size_t)hf * row);
+    if (rc) {
+        h->stage_open = false;
+        return rc;
+    }
+    return piehip_run_staged(h, results);
 }
 
 int piehip_run_host_wait(piehip_handle h)

@@ -8,11 +8,17 @@
 // for everything the library reports at run time).
 //
 // The reference class is written against lbcrypto::Ciphertext<DCRTPoly> / lbcrypto::Plaintext.  OpenFHE is
-// not available to this build, so the facade is a template over a small "limb traits" adapter: anything that
-// can copy its RNS towers (EVALUATION format, uint64_t[N] each) into and out of a flat buffer.  piehip::LimbCt /
-// piehip::LimbPt below are the plain-memory instances the tests use; INTEGRATION.md gives the OpenFHE instance
+// not available to this build, so ciphertexts are piehip::LimbCt here: the RNS towers of a DCRTPoly pair (EVALUATION
+// format, uint64_t[N] each) as one flat array.  INTEGRATION.md gives the OpenFHE binding
 // (DCRTPoly::GetElementAtIndex(i).GetValues() <-> limb arrays), which is the only code a maintainer adds.
+//
+// Host path.  The query lives in page-locked staging arrays owned by the library (piehip_host_buffers); setIndex /
+// setMinusCompareElement copy each ciphertext there exactly once and start the upload of every piece as soon as it is complete
+// (piehip_stage_*), run() is piehip_run_staged (+ wait), and the result list is read from the page-locked result array.  A
+// deserialiser can skip the copy altogether: it writes the towers straight into indexStaging(h, j) / minusStaging() and calls
+// stageIndexCiphertext(h, j) / stageMinus() (BatchedFHEPSIServer.hpp does; INTEGRATION.md section 2 shows it with OpenFHE).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <random>
@@ -117,7 +123,7 @@ public:
         // bin-layer shuffle (.cpp:23-35), gather (.cpp:45-70), masks (.cpp:72-82) and MakePackedPlaintext (.cpp:68,81),
         // all on the device
         PieContext::check(piehip_load_db_table(cc.handle(), hct.table, k, e, K, b, E, shuffleSeed, maskSeed));
-        resultList.resize(b);
+        initStaging();
     }
 
     // A further query slot on `database`'s packed table and on its context's key (piehip_attach_database): `cryptoContext`
@@ -128,7 +134,7 @@ public:
     {
         K = database.K, b = database.b, E = database.E;
         PieContext::check(piehip_attach_database(cc.handle(), database.cc.handle()));
-        resultList.resize(b);
+        initStaging();
     }
 
     void run()  // BatchedFHEHIPPIE.cpp:88-129
@@ -136,44 +142,101 @@ public:
         enqueue();
         collect();
     }
-    // run() in two halves: the evaluation is asynchronous on the device; collect() waits for it and fills the result list
-    void enqueue() { PieContext::check(piehip_run(cc.handle())); }
+    // run() in two halves: the evaluation and the download of the result list are asynchronous; collect() waits for them
+    void enqueue()
+    {
+        if (minusStaged && rowsStaged == K) {
+            PieContext::check(piehip_run_staged(cc.handle(), pinRes));
+        } else if (minusStaged || rowsStaged || arrived) {
+            throw std::runtime_error("run: setMinusCompareElement and setIndex must both precede run()");
+        } else {
+            // the query of the previous run() again (its inputs are still in HBM)
+            PieContext::check(piehip_run(cc.handle()));
+            rerun = true;
+        }
+        minusStaged = false;
+        rowsStaged = 0;
+        std::fill(rowCount.begin(), rowCount.end(), 0u);
+        arrived = 0;
+    }
     void collect()
     {
-        const size_t ct = 2 * (size_t)cc.towers() * cc.ringDimension();
-        std::vector<uint64_t> flat(ct * b);
-        PieContext::check(piehip_get_results(cc.handle(), flat.data()));
-        for (uint32_t i = 0; i < b; i++) resultList[i].limbs.assign(flat.begin() + i * ct, flat.begin() + (i + 1) * ct);
+        if (rerun) PieContext::check(piehip_get_results(cc.handle(), pinRes));
+        else PieContext::check(piehip_run_host_wait(cc.handle()));
+        rerun = false;
+        listStale = true;
     }
 
-    std::vector<LimbCt> &getResultList() { return resultList; }  // .hpp:35-38
+    // .hpp:35-38.  The ciphertexts are materialised from the page-locked result array on the first call after a run() (the
+    // reference's timer has stopped by then: BatchedFHEPSIServer.cpp:105-108); resultTowers(i) reads them in place.
+    std::vector<LimbCt> &getResultList()
+    {
+        if (listStale) {
+            const size_t ct = ctWords();
+            for (uint32_t i = 0; i < b; i++) resultList[i].limbs.assign(pinRes + (size_t)i * ct, pinRes + (size_t)(i + 1) * ct);
+            listStale = false;
+        }
+        return resultList;
+    }
+    const uint64_t *resultTowers(uint32_t i) const { return pinRes + (size_t)i * ctWords(); }  // [2][L][N], valid until the next run()
 
     void setIndex(std::vector<std::vector<LimbCt>> &&indexMatrix)  // .hpp:40-43, [K][E] ciphertexts
     {
-        const size_t ct = 2 * (size_t)cc.towers() * cc.ringDimension();
+        const size_t ct = ctWords();
         if (indexMatrix.size() != K) throw std::invalid_argument("index matrix must have one row per inner hash function");
-        std::vector<uint64_t> flat((size_t)K * E * ct);
         for (uint32_t h = 0; h < K; h++) {
             if (indexMatrix[h].size() != E) throw std::invalid_argument("index matrix row length must be eachCuckooTableSize");
-            for (uint32_t j = 0; j < E; j++) {
+            for (uint32_t j = 0; j < E; j++)
                 if (indexMatrix[h][j].limbs.size() != ct) throw std::invalid_argument("ciphertext does not match the context");
-                std::memcpy(&flat[((size_t)h * E + j) * ct], indexMatrix[h][j].limbs.data(), ct * sizeof(uint64_t));
-            }
         }
-        PieContext::check(piehip_set_index(cc.handle(), flat.data()));
+        for (uint32_t h = 0; h < K; h++)
+            for (uint32_t j = 0; j < E; j++) {  // one copy, straight into the staging array; row h uploads while row h + 1 is copied
+                std::memcpy(indexStaging(h, j), indexMatrix[h][j].limbs.data(), ct * sizeof(uint64_t));
+                stageIndexCiphertext(h, j);
+            }
     }
 
     void setMinusCompareElement(LimbCt minusCompareElement)  // .hpp:45-48
     {
-        if (minusCompareElement.limbs.size() != 2 * (size_t)cc.towers() * cc.ringDimension())
-            throw std::invalid_argument("ciphertext does not match the context");
-        PieContext::check(piehip_set_minus(cc.handle(), minusCompareElement.limbs.data()));
+        if (minusCompareElement.limbs.size() != ctWords()) throw std::invalid_argument("ciphertext does not match the context");
+        std::memcpy(minusStaging(), minusCompareElement.limbs.data(), ctWords() * sizeof(uint64_t));
+        stageMinus();
+    }
+
+    // ---- zero-copy variant of the two setters, for a deserialiser ------------------------------------------------------------
+    uint64_t *indexStaging(uint32_t h, uint32_t j) { return pinIdx + ((size_t)h * E + j) * ctWords(); }  // [2][L][N] of idx[h][j]
+    uint64_t *minusStaging() { return pinMinus; }
+    // ciphertext (h, j) has been written to indexStaging(h, j); the row's upload starts when its E ciphertexts have arrived
+    void stageIndexCiphertext(uint32_t h, uint32_t j)
+    {
+        if (h >= K || j >= E) throw std::invalid_argument("index matrix position out of range");
+        arrived++;
+        if (++rowCount[h] == E) {
+            PieContext::check(piehip_stage_index_row(cc.handle(), h, indexStaging(h, 0)));
+            rowsStaged++;
+        }
+    }
+    void stageMinus()
+    {
+        PieContext::check(piehip_stage_minus(cc.handle(), pinMinus));
+        minusStaged = true;
     }
 
 protected:
+    size_t ctWords() const { return 2 * (size_t)cc.towers() * cc.ringDimension(); }
+    void initStaging()
+    {
+        PieContext::check(piehip_host_buffers(cc.handle(), &pinIdx, &pinMinus, &pinRes));
+        resultList.resize(b);
+        rowCount.assign(K, 0u);
+    }
     PieContext &cc;
     uint32_t K = 0, b = 0, E = 0;
     std::vector<LimbCt> resultList;
+    uint64_t *pinIdx = nullptr, *pinMinus = nullptr, *pinRes = nullptr;  // page-locked, owned by the library
+    std::vector<uint32_t> rowCount;
+    uint32_t rowsStaged = 0, arrived = 0;
+    bool minusStaged = false, rerun = false, listStale = false;
 };
 
 }  // namespace piehip

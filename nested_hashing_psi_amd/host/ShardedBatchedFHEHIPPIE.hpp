@@ -7,6 +7,10 @@
 // same seeds), the per-query inputs replicated, run() enqueued on all devices before any is waited for, and the result list
 // assembled in bin order -- each device copies its slice straight to host memory over its own PCIe link (the list leaves
 // through sendResult, .cpp:143-152, so no peer copy to a "device 0" is needed).
+// Host path: the query is copied once into the first shard's page-locked staging arrays; every piece (the minus element, each
+// row of the index matrix) is then queued for upload on ALL shards at once (piehip_stage_*: asynchronous, one PCIe link per
+// device), run() is piehip_run_staged on every shard followed by one wait per shard, and each shard's slice of the result
+// list lands in that shard's page-locked result array.
 // Same methods, call order and exceptions as BatchedFHEHIPPIE.hpp; one host thread drives all handles (the handles' own HIP
 // streams run concurrently).  torchrun / one process per GPU with the RCCL gather is the other way to shard (bench.py).
 #pragma once
@@ -49,40 +53,62 @@ public:
             slices.push_back({lo, hi});
         }
         resultList.resize(b);
-        const size_t ct = ctWords();
-        flat.resize((size_t)b * ct);
+        pinRes.resize(G);
+        for (uint32_t g = 0; g < G; g++) {
+            uint64_t *pi = nullptr, *pm = nullptr;
+            PieContext::check(piehip_host_buffers(ccs[g]->handle(), &pi, &pm, &pinRes[g]));
+            if (g == 0) pinIdx = pi, pinMinus = pm;
+        }
     }
 
     void run()  // BatchedFHEHIPPIE.cpp:88-129 on every shard
     {
-        for (size_t g = 0; g < slices.size(); g++) PieContext::check(piehip_run(ccs[g]->handle()));  // asynchronous: all devices busy
-        const size_t ct = ctWords();
-        for (size_t g = 0; g < slices.size(); g++)
-            PieContext::check(piehip_get_results(ccs[g]->handle(), &flat[(size_t)slices[g].lo * ct]));
-        for (uint32_t i = 0; i < b; i++) resultList[i].limbs.assign(flat.begin() + (size_t)i * ct, flat.begin() + (size_t)(i + 1) * ct);
+        if (!minusStaged || rowsStaged != K) throw std::runtime_error("run: setMinusCompareElement and setIndex must both precede run()");
+        for (size_t g = 0; g < slices.size(); g++) PieContext::check(piehip_run_staged(ccs[g]->handle(), pinRes[g]));  // all devices busy
+        for (size_t g = 0; g < slices.size(); g++) PieContext::check(piehip_run_host_wait(ccs[g]->handle()));
+        minusStaged = false;
+        rowsStaged = 0;
+        listStale = true;
     }
 
-    std::vector<LimbCt> &getResultList() { return resultList; }  // .hpp:35-38
+    std::vector<LimbCt> &getResultList()  // .hpp:35-38; materialised from the shards' result arrays on the first call after run()
+    {
+        if (listStale) {
+            const size_t ct = ctWords();
+            for (size_t g = 0; g < slices.size(); g++)
+                for (uint32_t i = slices[g].lo; i < slices[g].hi; i++) {
+                    const uint64_t *src = pinRes[g] + (size_t)(i - slices[g].lo) * ct;
+                    resultList[i].limbs.assign(src, src + ct);
+                }
+            listStale = false;
+        }
+        return resultList;
+    }
 
     void setIndex(std::vector<std::vector<LimbCt>> &&indexMatrix)  // .hpp:40-43, [K][E] ciphertexts, replicated to every shard
     {
         const size_t ct = ctWords();
         if (indexMatrix.size() != K) throw std::invalid_argument("index matrix must have one row per inner hash function");
-        std::vector<uint64_t> buf((size_t)K * E * ct);
         for (uint32_t h = 0; h < K; h++) {
             if (indexMatrix[h].size() != E) throw std::invalid_argument("index matrix row length must be eachCuckooTableSize");
-            for (uint32_t j = 0; j < E; j++) {
+            for (uint32_t j = 0; j < E; j++)
                 if (indexMatrix[h][j].limbs.size() != ct) throw std::invalid_argument("ciphertext does not match the context");
-                std::memcpy(&buf[((size_t)h * E + j) * ct], indexMatrix[h][j].limbs.data(), ct * sizeof(uint64_t));
-            }
         }
-        for (size_t g = 0; g < slices.size(); g++) PieContext::check(piehip_set_index(ccs[g]->handle(), buf.data()));
+        for (uint32_t h = 0; h < K; h++) {
+            uint64_t *row = pinIdx + (size_t)h * E * ct;
+            for (uint32_t j = 0; j < E; j++) std::memcpy(row + (size_t)j * ct, indexMatrix[h][j].limbs.data(), ct * sizeof(uint64_t));
+            // the row leaves for every device at once, while the next row is being copied
+            for (size_t g = 0; g < slices.size(); g++) PieContext::check(piehip_stage_index_row(ccs[g]->handle(), h, row));
+        }
+        rowsStaged = K;
     }
 
     void setMinusCompareElement(LimbCt minusCompareElement)  // .hpp:45-48
     {
         if (minusCompareElement.limbs.size() != ctWords()) throw std::invalid_argument("ciphertext does not match the context");
-        for (size_t g = 0; g < slices.size(); g++) PieContext::check(piehip_set_minus(ccs[g]->handle(), minusCompareElement.limbs.data()));
+        std::memcpy(pinMinus, minusCompareElement.limbs.data(), ctWords() * sizeof(uint64_t));
+        for (size_t g = 0; g < slices.size(); g++) PieContext::check(piehip_stage_minus(ccs[g]->handle(), pinMinus));
+        minusStaged = true;
     }
 
     struct Slice {
@@ -96,7 +122,10 @@ private:
     std::vector<Slice> slices;
     uint32_t K = 0, b = 0, E = 0;
     std::vector<LimbCt> resultList;
-    std::vector<uint64_t> flat;
+    uint64_t *pinIdx = nullptr, *pinMinus = nullptr;  // the first shard's page-locked staging arrays: the source of every upload
+    std::vector<uint64_t *> pinRes;                  // per shard: its slice of the result list, page-locked
+    uint32_t rowsStaged = 0;
+    bool minusStaged = false, listStale = false;
 };
 
 }  // namespace piehip

@@ -92,28 +92,41 @@ inline std::vector<uint8_t> packCiphertexts(const uint64_t *limbs, uint32_t coun
     std::memcpy(msg.data() + sizeof(h), limbs, words * sizeof(uint64_t));
     return msg;
 }
-// returns the ciphertext count; throws if the message does not describe [count][2][L][N].  moduli (q_0..q_{L-1}, may be null):
-// every residue of limb i must be canonical, i.e. below q_i -- the device kernels assume it (lazy accumulation), and what
-// arrives here comes from the other party.
+// every residue of limb i must be canonical, i.e. below moduli[i % L] -- the device kernels assume it (lazy accumulation), and
+// what arrives here comes from the other party
+inline void checkCanonical(const uint64_t *limbs, size_t nlimbs, uint32_t L, uint32_t N, const uint64_t *moduli, const char *what)
+{
+    for (size_t limb = 0; limb < nlimbs; limb++) {
+        const uint64_t q = moduli[limb % L], *p = limbs + limb * N;
+        uint64_t bad = 0;
+        for (uint32_t j = 0; j < N; j++) bad |= (uint64_t)(p[j] >= q);
+        if (bad) throw std::invalid_argument(std::string(what) + " residue not below its modulus");
+    }
+}
+// Unpacks straight into caller memory (e.g. the page-locked staging array the upload starts from): dst[count][2][L][N] must
+// hold `expect` ciphertexts.  Throws if the message does not describe [expect][2][L][N] or (moduli != null: q_0..q_{L-1}) a
+// residue is not canonical.
+inline void unpackCiphertextsInto(const std::vector<uint8_t> &msg, uint32_t L, uint32_t N, uint64_t *dst, uint32_t expect,
+                                  const uint64_t *moduli = nullptr)
+{
+    if (msg.size() < sizeof(LimbHeader)) throw std::invalid_argument("short ciphertext message");
+    LimbHeader h;
+    std::memcpy(&h, msg.data(), sizeof(h));
+    if (h.magic != 0x48454950u || h.L != L || h.N != N || h.count != expect) throw std::invalid_argument("ciphertext message does not match the context");
+    const size_t words = (size_t)h.count * 2 * L * N;
+    if (msg.size() != sizeof(LimbHeader) + words * sizeof(uint64_t)) throw std::invalid_argument("ciphertext message length mismatch");
+    std::memcpy(dst, msg.data() + sizeof(h), words * sizeof(uint64_t));
+    if (moduli) checkCanonical(dst, (size_t)h.count * 2 * L, L, N, moduli, "ciphertext");
+}
+// returns the ciphertext count; throws if the message does not describe [count][2][L][N]
 inline uint32_t unpackCiphertexts(const std::vector<uint8_t> &msg, uint32_t L, uint32_t N, std::vector<uint64_t> &limbs,
                                   const uint64_t *moduli = nullptr)
 {
     if (msg.size() < sizeof(LimbHeader)) throw std::invalid_argument("short ciphertext message");
     LimbHeader h;
     std::memcpy(&h, msg.data(), sizeof(h));
-    if (h.magic != 0x48454950u || h.L != L || h.N != N) throw std::invalid_argument("ciphertext message does not match the context");
-    const size_t words = (size_t)h.count * 2 * L * N;
-    if (msg.size() != sizeof(LimbHeader) + words * sizeof(uint64_t)) throw std::invalid_argument("ciphertext message length mismatch");
-    limbs.resize(words);
-    std::memcpy(limbs.data(), msg.data() + sizeof(h), words * sizeof(uint64_t));
-    if (moduli) {
-        for (size_t limb = 0; limb < (size_t)h.count * 2 * L; limb++) {
-            const uint64_t q = moduli[limb % L], *p = &limbs[limb * N];
-            uint64_t bad = 0;
-            for (uint32_t j = 0; j < N; j++) bad |= (uint64_t)(p[j] >= q);
-            if (bad) throw std::invalid_argument("ciphertext residue not below its modulus");
-        }
-    }
+    limbs.resize((size_t)h.count * 2 * L * N);
+    unpackCiphertextsInto(msg, L, N, limbs.data(), h.count, moduli);
     return h.count;
 }
 

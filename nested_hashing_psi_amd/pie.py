@@ -234,6 +234,16 @@ class BatchedFHEHIPPIE:
         # database must be given the same seeds
         if binSlice is not None and serverSet is None and hashTable is None:
             raise ValueError("binSlice applies to databases built from a server set or a hash table")
+        if binSlice is not None:
+            # every shard builds (or shuffles) the whole table and keeps its slice: with seeds drawn per rank the ranks would cut
+            # slices out of different tables -- items in two shards or in none, silent false negatives.  The seeds of a sharded
+            # database are therefore the caller's to distribute (drawn once, e.g. on rank 0, and broadcast: shard.shared_seeds).
+            hp_ = hashParams or {}
+            given = [hp_.get("shuffle_seed", shuffle_seed), hp_.get("mask_seed", mask_seed)]
+            if serverSet is not None:
+                given.append(hp_.get("evict_seed"))
+            if any(v is None for v in given):
+                raise ValueError("binSlice needs explicit evict / shuffle / mask seeds, identical on every shard of the database")
         if attachTo is not None:
             # a further query slot on attachTo's database and key (piehip_attach_database): own context, stream and workspace
             self.K, self.b, self.E = attachTo.K, attachTo.b, attachTo.E
@@ -346,6 +356,24 @@ class BatchedFHEHIPPIE:
             raise ValueError("index matrix must be [K][E] ciphertexts, the minus element one ciphertext, results [b] ciphertexts")
         _check(lib().piehip_run_host_async(self.cc._h, indexMatrix.ctypes.data_as(u64p), minusCompareElement.ctypes.data_as(u64p),
                                            results.ctypes.data_as(u64p)))
+
+    def stageMinus(self, minusCompareElement):
+        """start the upload of the minus element (piehip_stage_minus); the array must stay untouched until waitHost()"""
+        if minusCompareElement.dtype != np.uint64 or not minusCompareElement.flags.c_contiguous or minusCompareElement.shape != (2, self.cc.L, self.cc.N):
+            raise ValueError("the minus element is one contiguous uint64 ciphertext")
+        _check(lib().piehip_stage_minus(self.cc._h, minusCompareElement.ctypes.data_as(u64p)))
+
+    def stageIndexRow(self, row, rowCiphertexts):
+        """start the upload of row `row` of the index matrix, [E][2][L][N] (piehip_stage_index_row)"""
+        if rowCiphertexts.dtype != np.uint64 or not rowCiphertexts.flags.c_contiguous or rowCiphertexts.shape != (self.E, 2, self.cc.L, self.cc.N):
+            raise ValueError("an index matrix row is E contiguous uint64 ciphertexts")
+        _check(lib().piehip_stage_index_row(self.cc._h, int(row), rowCiphertexts.ctypes.data_as(u64p)))
+
+    def runStaged(self, results):
+        """evaluate the staged query and queue the download of the result list (piehip_run_staged); waitHost() completes it"""
+        if results.dtype != np.uint64 or not results.flags.c_contiguous or results.shape != (self.b, 2, self.cc.L, self.cc.N):
+            raise ValueError("results must be [b] contiguous uint64 ciphertexts")
+        _check(lib().piehip_run_staged(self.cc._h, results.ctypes.data_as(u64p)))
 
     def waitHost(self):
         """block until the results of the last runHostAsync are complete in host memory"""

@@ -4,6 +4,7 @@
 //  2. ShardedBatchedFHEHIPPIE over three contexts (all on the one visible device, as three devices of a node would be)
 //     returns, bit for bit, the result list of the unsharded BatchedFHEHIPPIE given the same seeds.
 // Exit code 0 = ok, 77 = no GPU.
+#include <chrono>
 #include <cstdio>
 #include <vector>
 
@@ -35,6 +36,7 @@ static void fill_ct(std::vector<uint64_t> &v, const std::vector<uint64_t> &mod, 
             for (uint32_t j = 0; j < N; j++) v[((size_t)c * L + i) * N + j] = mix(seed) % mod[i];
 }
 
+static long long g_last_query_us = 0;  // setMinusCompareElement + setIndex + run of the last query()
 template <class Op>
 static std::vector<std::vector<uint64_t>> query(Op &op, PieContext &cc, uint32_t K, uint32_t E, uint64_t seed)
 {
@@ -44,9 +46,11 @@ static std::vector<std::vector<uint64_t>> query(Op &op, PieContext &cc, uint32_t
     std::vector<std::vector<LimbCt>> idx(K, std::vector<LimbCt>(E));
     for (auto &row : idx)
         for (auto &c : row) fill_ct(c.limbs, mod, cc.towers(), cc.ringDimension(), seed);
+    const auto t0 = std::chrono::steady_clock::now();
     op.setMinusCompareElement(minus);
     op.setIndex(std::move(idx));
     op.run();
+    g_last_query_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
     std::vector<std::vector<uint64_t>> out;
     for (auto &c : op.getResultList()) out.push_back(c.limbs);
     return out;
@@ -125,7 +129,11 @@ int main()
         }
         for (uint64_t s : {100ull, 300ull}) {
             const auto want = query(opA, ccA, 2, 3, s);
+            const long long one_us = g_last_query_us;
             const auto got = query(sh, c0, 2, 3, s);
+            // three handles: the uploads and runs of all shards are queued before any is waited for
+            std::printf("query %llu: one handle %lld us, three shards (uploads and runs overlapped) %lld us\n", (unsigned long long)s, one_us,
+                        g_last_query_us);
             if (got != want) {
                 std::printf("sharded result differs from the unsharded one (query %llu)\n", (unsigned long long)s);
                 return 4;

@@ -148,3 +148,23 @@ def test_client_parameter_selection_follows_the_reference():
     assert select_parameters(48, 5000)["depth"] == 10 and select_parameters(40, 1)["t"] == 1099579260929
     with pytest.raises(ValueError):
         select_parameters(24, 10)
+
+
+def test_sharded_database_needs_explicit_seeds():
+    """a bin-slice shard built with seeds of its own would be a slice of a different table than its peers': the
+    mirror refuses missing evict / shuffle / mask seeds before anything reaches the library"""
+    import types
+
+    import numpy as np
+    import pytest
+    from nested_hashing_psi_amd import pie
+    cc = types.SimpleNamespace(_h=None, L=2, N=64)
+    items = np.arange(1, 40, dtype=np.uint64)
+    base = dict(k=2, e=4, K=2, b=4, E=4)
+    for missing in ("evict_seed", "shuffle_seed", "mask_seed"):
+        hp = dict(base, evict_seed=1, shuffle_seed=2, mask_seed=3)
+        del hp[missing]
+        with pytest.raises(ValueError, match="identical on every shard"):
+            pie.BatchedFHEHIPPIE(cc, serverSet=items, hashParams=hp, binSlice=(0, 2))
+    with pytest.raises(ValueError, match="identical on every shard"):
+        pie.BatchedFHEHIPPIE(cc, hashTable=np.zeros((2, 4, 2, 4, 4), dtype=np.uint64), shuffle_seed=5, binSlice=(0, 2))

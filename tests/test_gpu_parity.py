@@ -581,6 +581,17 @@ def test_query_slots_on_one_database(ob, pie, N, L, K, E, b, depth):
         pipe.slots[1].cc.load_relin_key(evk)
     with pytest.raises(RuntimeError):   # the owner's buffers may not move while slots are attached
         pie.BatchedFHEHIPPIE(cc, vectorizedHCT=rand_limbs(rng, cc.q, (K, 2, E), N), preCalcRandomMask=rand_limbs(rng, cc.q, (2,), N))
+    with pytest.raises(RuntimeError):   # ... nor be rewritten in place (same shape): the slots read them on their own streams
+        pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    with pytest.raises(RuntimeError):
+        cc.load_relin_key(evk)
+    with pytest.raises(RuntimeError):   # ... nor may the owner drop them by attaching itself elsewhere
+        pie.BatchedFHEHIPPIE(cc, attachTo=pipe.slots[1])
+    for s, (idx, minus) in zip(pipe.slots, queries):   # nothing was freed or overwritten by the refused calls
+        s.setMinusCompareElement(minus)
+        s.setIndex(idx)
+        s.run()
+        assert (s.getResultList() == o.pie_run(idx, minus, db, masks, evk)).all()
     # a slot with a database of its own: detached, the owner's buffers untouched
     db2, masks2 = rand_limbs(rng, cc.q, (K, 3, E), N), rand_limbs(rng, cc.q, (3,), N)
     c1 = pipe.slots[1].cc
@@ -695,6 +706,92 @@ def test_run_shape_extremes(ob, pie, E, b):
     op.setIndex(idx)
     op.run()
     assert (op.getResultList() == o.pie_run(idx, minus, db, masks, evk)).all()
+    cc.close()
+
+
+@pytest.mark.parametrize("N,L,t,E,b", [(4096, 2, T16, 6, 5), (16384, 4, T32, 4, 9)])
+def test_run_with_one_inner_hash_function(ob, pie, N, L, t, E, b):
+    """K = 1 (BatchedFHEHIPPIE.cpp:117-120,126): multipliedResult is the inner product itself, run() = stage A + mask multiply;
+    no relinearisation key is needed.  Ciphertext bits vs the oracle, decrypted semantics, every entry point of run()."""
+    K = 1
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(N + E)
+    sk = o.keygen(5)
+    B = 24
+    # a table with one inner hash function: cell [bin][j][slot]; the client in slot s selects position pos[s] and asks for x[s]
+    cells = rng.integers(1, t, (K, b, E, B), dtype=np.int64)
+    pos = rng.integers(0, E, B)
+    x = rng.integers(1, t, B, dtype=np.int64)
+    hit = rng.random(B) < 0.5
+    hit_bin = rng.integers(0, b, B)
+    for s in np.nonzero(hit)[0]:
+        cells[0, hit_bin[s], pos[s], s] = x[s]
+    mask_slots = rng.integers(1, t, (b, B), dtype=np.int64)
+    index = np.zeros((K, E, B), dtype=np.int64)
+    index[0, pos, np.arange(B)] = 1
+    idx = np.stack([o.encrypt_slots(sk, index[0, j], 40 + j) for j in range(E)]).reshape(K, E, 2, L, N)
+    minus = o.encrypt_slots(sk, -x, 39)
+    db = np.stack([o.encode_eval(cells[0, bn, j]) for bn in range(b) for j in range(E)]).reshape(K, b, E, L, N)
+    masks = np.stack([o.encode_eval(mask_slots[bn]) for bn in range(b)])
+    want = o.pie_run(idx, minus, db, masks, np.zeros((L, 2, L, N), dtype=np.uint64))
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)   # no key loaded
+    op.setMinusCompareElement(minus)
+    op.setIndex(idx)
+    op.run()
+    got = op.getResultList().copy()
+    assert (got == want).all()
+    for streams in (1, 0):
+        cc.set_run_streams(streams)
+        assert (op.runHost(idx, minus) == want).all()
+    op2 = pie.BatchedFHEHIPPIE(cc, slots=cells, mask_slots=mask_slots)
+    op2.setMinusCompareElement(minus)
+    op2.setIndex(idx)
+    op2.run()
+    assert (op2.getResultList() == want).all()
+    dec = np.stack([o.decrypt_slots(sk, got[bn], B)[0] for bn in range(b)])
+    zero = (dec == 0)
+    for s in range(B):
+        expect = set(np.nonzero(cells[0, :, pos[s], s] == x[s])[0])
+        assert set(np.nonzero(zero[:, s])[0]) == expect
+    # the hashing entry points refuse one inner hash function as the reference's CuckooHashTable does (CuckooHashTable.cpp:39-42)
+    with pytest.raises(ValueError, match="more than one hash function"):
+        pie.BatchedFHEHIPPIE(cc, serverSet=np.arange(1, 50, dtype=np.uint64), hashParams=dict(k=2, e=8, K=1, b=4, E=4, evict_seed=1,
+                                                                                            shuffle_seed=2, mask_seed=3))
+    cc.close()
+
+
+def test_staged_query_upload(ob, pie):
+    """piehip_stage_minus / piehip_stage_index_row / piehip_run_staged: the pieces of a query uploaded as a server receives them
+    (any order), evaluated when all have been staged; a missing piece is a call-order error; the one-call form still works"""
+    N, L, t, K, E, b = 4096, 2, T16, 3, 4, 9
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(77)
+    db, masks, evk = rand_limbs(rng, cc.q, (K, b, E), N), rand_limbs(rng, cc.q, (b,), N), rand_limbs(rng, cc.q, (L, 2), N)
+    cc.load_relin_key(evk)
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    pi, pm, pr = op.hostBuffers()
+    for order in ([0, 1, 2], [2, 0, 1]):
+        idx, minus = rand_limbs(rng, cc.q, (K, E, 2), N), rand_limbs(rng, cc.q, (2,), N)
+        pi[...] = idx
+        pm[...] = minus
+        pr[...] = 0
+        op.stageIndexRow(order[0], pi[order[0]])
+        op.stageMinus(pm)
+        with pytest.raises(RuntimeError, match="not staged"):
+            op.runStaged(pr)
+        op.stageIndexRow(order[1], pi[order[1]])
+        op.stageIndexRow(order[2], pi[order[2]])
+        op.runStaged(pr)
+        op.waitHost()
+        assert (pr == o.pie_run(idx, minus, db, masks, evk)).all()
+    with pytest.raises(RuntimeError, match="not staged"):   # nothing staged since the last run
+        op.runStaged(pr)
+    with pytest.raises(ValueError):
+        op.stageIndexRow(K, pi[0])
+    idx, minus = rand_limbs(rng, cc.q, (K, E, 2), N), rand_limbs(rng, cc.q, (2,), N)
+    assert (op.runHost(idx, minus) == o.pie_run(idx, minus, db, masks, evk)).all()
     cc.close()
 
 

@@ -110,7 +110,6 @@ int main(int argc, char **argv)
             a.data = d, a.twp = (const u64x2 *)d_twp, a.twk = (const u64x2 *)d_twk, a.dc = d_dc, a.N = N, a.s0 = s0, a.nitems = nitems;
             a.mod_base = 0, a.mod_count = nmod;
             a.flags = inv ? (F_FOLDED | (std_in ? F_STD_IN : 0)) : 0;
-            a.stagger_from = ~0u;
             a.lift_first = ~0u;
             if (inv)
                 hipLaunchKernelGGL(ntt16_kernel<true>, dim3(5), dim3(T), lds, 0, a);   // 5 blocks: every block loops
@@ -184,7 +183,6 @@ int main(int argc, char **argv)
         a.data = d, a.twp = (const u64x2 *)d_twp, a.twk = (const u64x2 *)d_twk, a.dc = d_dc, a.N = N, a.s0 = s0, a.nitems = nitems;
         a.mod_base = 0, a.mod_count = nmod;
         a.flags = F_LAZY_OUT;
-        a.stagger_from = ~0u;
         a.lift_first = ~0u;
         for (int rep = 0; rep < 400; rep++) hipLaunchKernelGGL(ntt16_kernel<false>, dim3(grid), dim3(T), lds, 0, a);
         CK(hipDeviceSynchronize());
@@ -218,8 +216,6 @@ int main(int argc, char **argv)
             a.flags = inv ? F_FOLDED : F_LAZY_OUT;
             const u32 grid = nitems < 512 ? nitems : 512;
             a.lift_first = ~0u;
-            a.stagger_from = 256;
-            a.stagger_sleeps = getenv("LAB_SLEEPS") ? atoi(getenv("LAB_SLEEPS")) : 0;
             hipEvent_t e0, e1;
             CK(hipEventCreate(&e0));
             CK(hipEventCreate(&e1));
