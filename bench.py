@@ -248,15 +248,38 @@ def synthetic_operator(pie, cc, cfg, b_local, rng, device_inputs):
     return op
 
 
-def time_runs(op, steps, warmup, sync):
-    for _ in range(warmup):
-        op.run(sync=False)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        op.run(sync=False)
-    sync()
-    return (time.perf_counter() - t0) / steps * 1e3
+WARM_SECONDS = 0.3   # warm-up of the timed region by TIME: clocks, caches, lazily created queues (whatever --warmup says)
+REPEATS = 15         # timed blocks of exactly --steps steps each; the median block is reported
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def timed_blocks(step, finish, steps, warmup, repeats=REPEATS, warm_seconds=WARM_SECONDS):
+    """ms per step: at least `warmup` steps and `warm_seconds` of warm-up, then `repeats` blocks of exactly `steps` steps, each
+    bracketed by finish() (drain + device synchronisation); returns (median, min, max) over the blocks"""
+    t_end = time.perf_counter() + warm_seconds
+    done = 0
+    while done < warmup or time.perf_counter() < t_end:
+        for _ in range(max(1, warmup)):
+            step()
+        done += max(1, warmup)
+        finish()
+    ts = []
+    for _ in range(repeats):
+        finish()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        finish()
+        ts.append((time.perf_counter() - t0) / steps * 1e3)
+    return median(ts), min(ts), max(ts)
+
+
+def time_runs(op, steps, warmup, sync, repeats=7, warm_seconds=0.1):
+    return timed_blocks(lambda: op.run(sync=False), sync, steps, warmup, repeats, warm_seconds)[0]
 
 
 def make_query_slots(torch, pie, cc, op, shape, depth, device, local_rank, gen, run_streams):
@@ -278,16 +301,14 @@ def make_query_slots(torch, pie, cc, op, shape, depth, device, local_rank, gen, 
     return slots
 
 
-def time_slots(ops, steps, warmup, sync):
+def time_slots(ops, steps, warmup, sync, repeats=7, warm_seconds=0.1):
     """ms per run() with the operators taking the steps round-robin (len(ops) queries in flight)"""
-    for i in range(warmup):
-        ops[i % len(ops)].run(sync=False)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        ops[i % len(ops)].run(sync=False)
-    sync()
-    return (time.perf_counter() - t0) / steps * 1e3
+    n = [0]
+
+    def step():
+        ops[n[0] % len(ops)].run(sync=False)
+        n[0] += 1
+    return timed_blocks(step, sync, steps, warmup, repeats, warm_seconds)[0]
 
 
 PROJECTION_IN_FLIGHT = 3
@@ -304,9 +325,22 @@ def projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, steps, wa
            "queries_in_flight": PROJECTION_IN_FLIGHT, "rows": {}}
     N, L, t = cfg["N"], cfg["L"], cfg["t"]
     sync = lambda: torch.cuda.synchronize(device)
+
+    def upload_ms(words):   # the query crossing PCIe from page-locked host memory: what every rank of a sharded server pays per query
+        h = torch.zeros(words, dtype=torch.int64).pin_memory()
+        d = torch.empty(words, dtype=torch.int64, device=device)
+        ts = []
+        for _ in range(12):
+            sync()
+            t0 = time.perf_counter()
+            d.copy_(h, non_blocking=True)
+            sync()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return median(ts[2:])
     for name, row in SCALING_ROWS.items():
         c2 = dict(cfg, **row)
         b = c2["b"]
+        up = upload_ms((c2["K"] * c2["E"] * 2 + 2) * L * N)
         shares = sorted({-(-b // G) for G in (1, 2, 4, 8)}, reverse=True)
         tms, tfl, graph_better = {}, {}, {}
         for n in shares:
@@ -325,7 +359,7 @@ def projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, steps, wa
             graph_better[n] = tg < te
             cc.set_run_streams(1)
             more = make_query_slots(torch, pie, cc, op, (N, L, t, c2["K"], c2["E"]), PROJECTION_IN_FLIGHT, device, local_rank, gen, 1)
-            tfl[n] = time_slots([op] + [m[1] for m in more], max(600, steps * 4), max(120, warmup * 4), sync)
+            tfl[n] = time_slots([op] + [m[1] for m in more], max(60, steps), max(12, warmup), sync)
             for m in reversed(more):
                 m[0].close()
             cc.close()
@@ -335,7 +369,13 @@ def projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, steps, wa
                              "speedup": {str(G): tms[b] / tms[-(-b // G)] for G in (2, 4, 8)},
                              "ms_per_run_in_flight": {str(n): tfl[n] for n in shares},
                              "speedup_in_flight": {str(G): tfl[b] / tfl[-(-b // G)] for G in (2, 4, 8)},
-                             "cap": {str(G): b / -(-b // G) for G in (2, 4, 8)}}
+                             "cap": {str(G): b / -(-b // G) for G in (2, 4, 8)},
+                             # "with query upload": every rank also receives the (K E + 1) query ciphertexts over its own PCIe link
+                             # (measured on this GPU, page-locked source).  serial = upload + share, nothing overlapped (one query
+                             # at a time); overlapped = max(upload, share): uploads of the next queries hidden behind the evaluation
+                             "query_upload_ms": up,
+                             "speedup_with_upload_serial": {str(G): (tms[b] + up) / (tms[-(-b // G)] + up) for G in (2, 4, 8)},
+                             "speedup_in_flight_with_upload_overlapped": {str(G): max(tfl[b], up) / max(tfl[-(-b // G)], up) for G in (2, 4, 8)}}
     return out
 
 
@@ -447,6 +487,13 @@ def main():
                          "over gloo (host-staged).  The timing means nothing; the line is marked")
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: run the RCCL gather path even with one rank (launch under torch.distributed.run)")
+    ap.add_argument("--repeats", type=int, default=REPEATS, help="timed blocks of --steps steps; the median block is reported")
+    ap.add_argument("--warm-seconds", type=float, default=WARM_SECONDS, help="minimum warm-up time before the timed blocks")
+    ap.add_argument("--query-dist", default="auto", choices=["auto", "broadcast", "scatter_gather", "none"],
+                    help="N > 1: how the per-query inputs travel from rank 0 to the ranks inside every step (auto: time both, keep "
+                         "the faster); none: every rank already holds them")
+    ap.add_argument("--query-source", default="hbm", choices=["hbm", "host"],
+                    help="N > 1: rank 0's copy of the query is resident in HBM (as at N = 1) or in page-locked host memory")
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line: libraries that print banners to fd 1 (RCCL's version block) go to stderr
@@ -557,41 +604,93 @@ def main():
         # one double-buffered gather per query slot (slots without bin layers still take part in the collective)
         rgs = [shard.ResultGather(s_[1], b_total, b_local, ct_words, device, s_[2], kind=args.collective) for s_ in slots]
         rg = rgs[0]
+    # Per-query input distribution (N > 1): the query ((K E + 1) ciphertexts) is resident in rank 0's HBM and reaches every rank
+    # through the slot's QueryBroadcast inside every step -- the second collective of the sharded server, after
+    # which the operator is pointed at the received copy.  --query-source host puts rank 0's copy in page-locked host memory
+    # instead (the reference server's situation; PCIe upload inside the step).
+    q_words, q_split = (K * E * 2 + 2) * L * N, K * E * 2 * L * N
+    qdist_kind, qdist_times = None, {}
+    if use_dist and args.query_dist != "none":
+        flat_q = torch.cat([idx.reshape(-1), minus.reshape(-1)])     # rank 0's copy is the one that counts
+        flat_h = flat_q.cpu().pin_memory() if args.query_source == "host" else None
+        kinds = ["broadcast", "scatter_gather"] if args.query_dist == "auto" else [args.query_dist]
+        if args.rehearse_on_one_gpu:
+            kinds = kinds[:1]
+        times = {}
+        for kind in kinds:
+            try:
+                probe = shard.QueryBroadcast(q_words, device, src=0, kind=kind)
+                probe.set_query_device(flat_q)
+                for rep in range(6):
+                    if rep == 1:
+                        torch.cuda.synchronize(device)
+                        dist.barrier()
+                        t_ = time.perf_counter()
+                    probe.step(rep & 1)
+                torch.cuda.synchronize(device)
+                tt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
+                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                times[kind] = float(tt_.item()) / 5
+                del probe
+            except (RuntimeError, NotImplementedError, ValueError) as exc:   # every rank fails alike
+                sys.stderr.write("query distribution %s unavailable: %s\n" % (kind, exc))
+        if times:
+            qdist_kind = min(times, key=times.get)
+            if rank == 0:
+                sys.stderr.write("query distribution timing (s per %.1f MiB query): %s -> %s\n" % (q_words * 8 / 2**20, times, qdist_kind))
+            for rg_ in rgs:
+                qb = shard.QueryBroadcast(q_words, device, src=0, kind=qdist_kind)
+                if flat_h is not None:
+                    qb.set_query_host(flat_h)
+                else:
+                    qb.set_query_device(flat_q)
+                rg_.query, rg_.query_split = qb, q_split
+            qdist_times = times
     nstep = [0]
 
     def step():
         i_ = nstep[0] % len(slots)
         nstep[0] += 1
         if rgs:
-            rgs[i_].step()      # run() into a gather buffer, then the path's only collective, double-buffered
+            rgs[i_].step()      # query distribution, run() into a gather buffer, gather of the results, double-buffered
         elif op is not None:
             slots[i_][1].run(sync=False)
 
-    def drain():
+    def finish():               # both sides of every timed block: collectives drained, device idle, ranks together
         for r_ in rgs:
             r_.drain()
+        torch.cuda.synchronize(device)
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        step()
-    drain()
-    torch.cuda.synchronize(device)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    torch.cuda.synchronize(device)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    ms_per_step = elapsed / args.steps * 1e3
+    def agree(x, how):          # a decision every rank must take alike (the ranks issue the same sequence of collectives)
+        if not dist:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
+        dist.all_reduce(tt, op=how)
+        return float(tt.item())
+
+    # Warm-up: at least --warmup steps and at least WARM_SECONDS of them (a 20-step block is 6 ms of GPU time; clocks, caches and
+    # the lazily created queues of every slot need longer than that), then REPEATS timed blocks of exactly --steps steps.
+    t_w = time.perf_counter()
+    done_w = 0
+    while True:
+        for _ in range(max(args.warmup, len(slots))):
+            step()
+        done_w += max(args.warmup, len(slots))
+        finish()
+        if agree(time.perf_counter() - t_w, dist.ReduceOp.MIN if dist else None) >= args.warm_seconds:
+            break
+    blocks = []
+    for _ in range(max(1, args.repeats)):
+        finish()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        finish()
+        blocks.append(agree(time.perf_counter() - t0, dist.ReduceOp.MAX if dist else None) / args.steps * 1e3)
+    ms_per_step = median(blocks)
 
     # per-kernel times of the same run(), HIP events on the launch stream (separate, untimed passes).  These passes are
     # serial (one stream): with the default two queues a kernel shares the chip with the other queue's kernels and its
@@ -600,18 +699,29 @@ def main():
     kernels = {}
     if op is not None and rank == 0:
         cc.set_run_streams(1)
-        cc.set_profiling(True)
-        agg = {}
-        for _ in range(max(1, args.profile_steps)):
+        # warm, then every recorded pass runs straight behind an unrecorded one (the device does not idle in between);
+        # per kernel class the MEDIAN pass is reported
+        t_end = time.perf_counter() + 0.15
+        while time.perf_counter() < t_end:
+            for _ in range(10):
+                op.run(sync=False)
+            torch.cuda.synchronize(device)
+        passes = []
+        for _ in range(max(3, args.profile_steps)):
+            cc.set_profiling(False)
+            op.run(sync=False)
+            cc.set_profiling(True)
             op.run(sync=True)
-            for name, rec in cc.profile().items():
-                a = agg.setdefault(name, dict(launches=0, ms=0.0, alg_bytes=0.0))
-                for key in a:
-                    a[key] += rec[key]
+            passes.append(cc.profile())
         cc.set_profiling(False)
         cc.set_run_streams(run_streams)
+        passes = passes[2:] if len(passes) > 4 else passes
+        agg = {}
+        for name in passes[0]:
+            recs = sorted((p_[name] for p_ in passes if name in p_), key=lambda r_: r_["ms"])
+            agg[name] = dict(recs[len(recs) // 2])
         for name, a in agg.items():
-            kernels[name] = dict(launches_per_step=a["launches"] / args.profile_steps, us_per_step=1e3 * a["ms"] / args.profile_steps,
+            kernels[name] = dict(launches_per_step=a["launches"], us_per_step=1e3 * a["ms"],
                                  alg_GBps=a["alg_bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else None)
         ntt_ms = sum(agg[n]["ms"] for n in ("ntt_fwd", "ntt_inv") if n in agg)
         ntt_bytes = sum(agg[n]["alg_bytes"] for n in ("ntt_fwd", "ntt_inv") if n in agg)
@@ -621,23 +731,29 @@ def main():
             roofline = {"kernel": "ntt (forward+inverse, LDS-resident limb)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config),
                         "avg_launch_us": 1e3 * ntt_ms / ntt_launch, "alg_bytes_per_launch": ntt_bytes / ntt_launch,
-                        "launches_per_step": ntt_launch / args.profile_steps,
-                        "measured": "HIP events around every launch, %d serial passes of run() (one stream; the timed region uses %s)"
-                                    % (args.profile_steps, "%d queue(s) per run(), %d queries in flight" % (run_streams or 2, in_flight))}
+                        "launches_per_step": ntt_launch,
+                        "measured": "HIP events around every launch, median of %d serial passes of run() after a warm-up (one stream; the "
+                                    "timed region uses %s)" % (len(passes), "%d queue(s) per run(), %d queries in flight" % (run_streams or 2, in_flight))}
 
     if rank == 0:
         value = b_total / (ms_per_step * 1e-3)
         cname = "C4 (C3's bin layers over %d GPUs)" % world if (world > 1 and scaling == "strong" and args.config == "C3") else args.config
         line = {
             "metric": "server PIE ciphertexts/sec", "value": value, "unit": "ciphertexts/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling if world > 1 else "n/a",
+            "repeats": len(blocks), "ms_per_step_min": min(blocks), "ms_per_step_max": max(blocks),
+            "timing": "median of %d blocks of exactly %d steps, each bracketed by barrier + synchronize, after >= %d steps and >= %.2f s "
+                      "of warm-up" % (len(blocks), args.steps, args.warmup, args.warm_seconds),
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%s: BatchedFHEHIPPIE::run(), N=%d, %d RNS primes (60-bit), t=%d, |S|=2^%d |C|=2^%d, k=%d e=%d (B=%d slots), "
                                    "K=%d E=%d, b=%d bin layers in all, %d on rank 0; %d ct x pt MACs + %d ct x ct (HPS + BV relin) + %d mask mults per step"
                                    % (cname, N, L, t, cfg["S"].bit_length() - 1, cfg["C"].bit_length() - 1, cfg["k"], cfg["e"], B, K, E,
                                       b_total, b_local, b_total * K * E, b_total * (K - 1), b_total),
                        "result_ciphertexts_per_step": b_total, "parallelism": "bins%d" % world,
-                       "collective": ("%s %s of results" % ("gloo (rehearsal)" if args.rehearse_on_one_gpu else "rccl", args.collective)) if use_dist else "none",
+                       "collective": ("%s: %s of the query from rank 0 (%s), %s of results"
+                                      % ("gloo (rehearsal)" if args.rehearse_on_one_gpu else "rccl", qdist_kind or "no distribution",
+                                         args.query_source, args.collective)) if use_dist else "none",
+                       "query_distribution_s": qdist_times,
                        "queries_in_flight": in_flight},
             "mac_per_s": b_total * K * E / (ms_per_step * 1e-3), "mul_per_s": b_total * (K - 1) / (ms_per_step * 1e-3),
             "queries_in_flight": in_flight, "run_streams": run_streams or 2, "hipgraph": bool(args.graph),
@@ -654,7 +770,7 @@ def main():
         if world == 1 and op is not None and in_flight > 1 and not args.bins_per_rank:
             # the same steps with one query at a time (one slot, the library's default of two queues per run())
             cc.set_run_streams(args.streams)
-            one_ms = time_runs(op, args.steps, args.warmup, lambda: torch.cuda.synchronize(device))
+            one_ms = time_runs(op, args.steps, args.warmup, lambda: torch.cuda.synchronize(device), repeats=args.repeats, warm_seconds=0.15)
             cc.set_run_streams(run_streams)
             line["one_query_at_a_time"] = {"ms_per_step": one_ms, "value": b_total / (one_ms * 1e-3), "run_streams": args.streams or 2}
         if world == 1 and op is not None and not args.no_ref_timer:

@@ -7,6 +7,12 @@ slice of bin layers, holds only that slice of the packed database, and the singl
 path is the final gather of result ciphertexts (RCCL over xGMI; `gloo` in the CPU tests): to the rank that
 answers the client (gather_bins_to), or to every rank (gather_bins).  With point-to-point xGMI links the
 gather to one rank moves each slice over its own link once; the all-gather moves 8x the bytes.
+
+The other exchange of a sharded server is per query, before run(): the index matrix and the minus element
+((K E + 1) 2 L W bytes, 29 MiB at the headline configuration) reach the server once (reference
+BatchedFHEPSIServer.cpp:94-95,114-141) and every rank needs all of them.  QueryBroadcast distributes them from
+the receiving rank; ResultGather.step() takes it as its first stage, so both collectives are in the sharded
+server's steady state.
 """
 import torch
 import torch.distributed as dist
@@ -70,6 +76,105 @@ def gather_bins_to(local, b, world, dst=0, out=None, group=None, async_op=False)
     return (out if rank == dst else None), work
 
 
+def shared_seeds(device=None, src=0, group=None):
+    """(evict, shuffle, mask) seeds of a sharded database: drawn once from the OS CSPRNG on rank `src` and broadcast, so that
+    every rank cuts its bin-layer slice out of the same table (pie.BatchedFHEHIPPIE(binSlice=...) requires explicit seeds)"""
+    import secrets
+    t = torch.zeros(3, dtype=torch.int64, device=device if dist.get_backend(group) != "gloo" else "cpu")
+    if dist.get_rank(group) == src:
+        t = torch.tensor([secrets.randbits(63) for _ in range(3)], dtype=torch.int64, device=t.device)
+    dist.broadcast(t, src=src, group=group)
+    return tuple(int(v) for v in t.cpu())
+
+
+class QueryBroadcast:
+    """Per-query input distribution of the sharded server: one flat array [K E 2 L N + 2 L N] (index matrix, then the minus
+    element) travels from rank `src` to every rank, double-buffered like the gather.
+
+    kind "broadcast":      dist.broadcast -- RCCL pipelines it round a ring, so the whole array crosses single links.
+    kind "scatter_gather": rank src sends a different 1/world of the array to every rank, then an all-gather completes it on
+                           all: with point-to-point xGMI every link carries 1/world of the bytes, twice.
+    source "hbm":  the query is resident in rank src's HBM when step() is called (set_query_device)
+    source "host": rank src holds it in page-locked host memory (set_query_host) and uploads it first -- the reference server's
+                   situation, PCIe included.
+    With the `gloo` backend (CPU tests, one-GPU rehearsals) the array is broadcast between host buffers and uploaded on every
+    rank.  Everything is enqueued on `in_stream`; ready(s) makes another stream wait for buffer set s."""
+
+    def __init__(self, words, device, src=0, kind="broadcast", group=None):
+        self.words, self.src, self.kind, self.group = words, src, kind, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"       # CPU: the gloo rehearsal of the sequence in the CPU tests (no streams)
+        self.host_staged = dist.get_backend(group) == "gloo"
+        self.in_stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self.chunk = -(-words // self.world)
+        padded = self.chunk * self.world
+        self.d_in = [torch.zeros(padded, dtype=torch.int64, device=self.device) for _ in range(2)]
+        self.d_mine = torch.zeros(self.chunk, dtype=torch.int64, device=self.device) if kind == "scatter_gather" else None
+        self.used = [False, False]
+        self.h_in = None
+        if self.host_staged and self.cuda:
+            self.h_in = [torch.zeros(padded, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.done = [torch.cuda.Event(), torch.cuda.Event()] if self.cuda else [None, None]   # buffer set s is complete on this rank
+        self.free = [None, None]                                  # ... and no longer read by the run that used it
+        self.host_query = None
+        self.dev_query = None
+
+    def set_query_host(self, flat):
+        """rank src: the next query as a page-locked int64 tensor [words] (other ranks: ignored)"""
+        self.host_query, self.dev_query = flat, None
+
+    def set_query_device(self, flat):
+        """rank src: the next query, resident in HBM"""
+        self.dev_query, self.host_query = flat, None
+
+    def release(self, s, event):
+        """the run that read buffer set s has been queued; `event` is recorded behind it"""
+        self.free[s] = event
+
+    def _distribute(self, buf):
+        if self.world == 1:
+            return
+        if self.kind == "scatter_gather" and not self.host_staged:   # (gloo: plain broadcast between host buffers)
+            parts = list(buf.view(self.world, self.chunk).unbind(0)) if self.rank == self.src else None
+            dist.scatter(self.d_mine, scatter_list=parts, src=self.src, group=self.group)
+            dist.all_gather_into_tensor(buf, self.d_mine, group=self.group)
+        else:
+            dist.broadcast(buf, src=self.src, group=self.group)
+
+    def step(self, s):
+        srcq = self.host_query if self.host_query is not None else self.dev_query
+        if not self.cuda:
+            if self.rank == self.src:
+                self.d_in[s][: self.words].copy_(srcq[: self.words])
+            self._distribute(self.d_in[s])
+            return
+        with torch.cuda.stream(self.in_stream):
+            if self.free[s] is not None:
+                self.in_stream.wait_event(self.free[s])
+            buf = self.d_in[s]
+            if self.host_staged:
+                h = self.h_in[s]
+                if self.used[s]:
+                    self.done[s].synchronize()       # the upload of the query that used this host buffer has finished
+                if self.rank == self.src:
+                    h[: self.words].copy_(srcq[: self.words])          # (device source: a blocking download, rehearsal only)
+                self._distribute(h)
+                buf.copy_(h, non_blocking=True)
+            else:
+                if self.rank == self.src:
+                    buf[: self.words].copy_(srcq[: self.words], non_blocking=True)
+                self._distribute(buf)
+            self.done[s].record(self.in_stream)
+            self.used[s] = True
+
+    def ready(self, s, stream=None):
+        if self.cuda:
+            stream.wait_event(self.done[s])
+        return self.d_in[s]
+
+
 class ResultGather:
     """The sharded server's steady state: run() of query i on this rank's bin layers, then the path's only collective --
     the gather of the result ciphertexts to the rank that answers the client (reference BatchedFHEPSIServer.cpp:143-152)
@@ -84,8 +189,12 @@ class ResultGather:
     buffers on the same stream and the host waits for that copy before the gather.
     """
 
-    def __init__(self, op, b, b_local, ct_words, device, stream, kind="gather", dst=0, group=None):
+    def __init__(self, op, b, b_local, ct_words, device, stream, kind="gather", dst=0, group=None, query=None, query_split=None):
+        """query: a QueryBroadcast -- step() then first distributes the next query from rank dst and points the operator at the
+        received copy; query_split = words of the index matrix (the minus element follows it in the flat array)"""
         self.op, self.b, self.dst, self.kind, self.group = op, b, dst, kind, group
+        self.query, self.query_split = query, query_split
+        self.run_done = [torch.cuda.Event(), torch.cuda.Event()]
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.stream = stream
@@ -112,12 +221,22 @@ class ResultGather:
     def step(self):
         s = self.i & 1
         self.i += 1
+        if self.query is not None:
+            self.query.step(s)                       # the inputs of this query: from rank dst to every rank (its own stream)
         with torch.cuda.stream(self.stream):
             if self.works[s] is not None:
                 self.works[s].wait()                 # buffer set s is free again (query i-2 gathered)
+            if self.query is not None:
+                flat = self.query.ready(s, self.stream)
+                if self.op is not None and self.b_local:
+                    self.op.setIndexDevice(flat.data_ptr())
+                    self.op.setMinusCompareElementDevice(flat.data_ptr() + 8 * self.query_split)
             if self.op is not None and self.b_local:
                 self.op.run(sync=False, into=self.my_out[s].data_ptr())
                 self.op.join()
+            if self.query is not None:
+                self.run_done[s].record(self.stream)
+                self.query.release(s, self.run_done[s])
             if self.host_staged:
                 self.staged[s].copy_(self.my_out[s], non_blocking=True)
                 self.stream.synchronize()

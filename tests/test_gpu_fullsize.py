@@ -3,9 +3,8 @@
 Each case is a real query end to end: the server set goes through the device's offline phase (nested hashing, Cuckoo
 insertion, bin shuffle, gather, packed encoding: piehip_build_db), the client's one-hot index matrix and minus vector are
 secret-key encrypted, run() evaluates them on the GPU, and the result must
-  (a) equal the oracle's restated run() (oracle/pie_oracle.c, reference BatchedFHEHIPPIE.cpp:88-129) bit for bit on the
-      bin layers compared -- all of them for C1, C2, C3; layers from both ends of each queue group for C5 (the oracle
-      needs 0.5 s per C5 layer);
+  (a) equal the oracle's restated run() (oracle/pie_oracle.c, reference BatchedFHEHIPPIE.cpp:88-129) bit for bit on every
+      bin layer of every configuration (the oracle needs 0.5 s per C5 layer: the layers are checked on a thread pool);
   (b) decrypt, with a positive noise budget in every result, to exactly the true intersection (reference check:
       src/Client/PSIClient.hpp:142-164);
 and the device-built hash table must equal the oracle's (same seeds).  "Bit for bit" is relative to the in-tree oracle:
@@ -71,12 +70,17 @@ def run_case(ob, pie, N, L, t, nS, nC, k, e, K, E, b, seed, compare_layers, stre
     found = ob.client_scan(ctab, np.stack(dec))
     assert len(found) == ninter
     assert sorted(int(v) for v in found) == sorted(int(v) for v in server[:ninter])
-    # (a) ciphertext bits
-    for bn in compare_layers:
+    # (a) ciphertext bits: bin layers are independent, one oracle task each (the C calls release the GIL)
+    import concurrent.futures
+
+    def layer_differs(bn):
         db = np.stack([o.encode_eval(slots[h, bn, j]) for h in range(K) for j in range(E)]).reshape(K, 1, E, L, N)
         masks = o.encode_eval(mask_slots[bn])[None]
         want = o.pie_run(idx, minus, db, masks, evk)
-        assert (got[bn] == want[0]).all(), "bin layer %d differs from the oracle" % bn
+        return bn if not (got[bn] == want[0]).all() else None
+    with concurrent.futures.ThreadPoolExecutor(max_workers=12) as pool:
+        bad = [bn for bn in pool.map(layer_differs, list(compare_layers)) if bn is not None]
+    assert not bad, "bin layers %s differ from the oracle" % bad
     return min(budgets)
 
 
@@ -102,9 +106,7 @@ def test_c5_full_size(ob, pie_mod):
     resident), E = 30 terms per inner product (the 128-bit stage-A kernel, not the carry-free one), K = 3 (two chained
     ct x ct), L = 6 base conversions on folded 2^14 slices, 30 bin layers split over the run queues."""
     b = 30
-    # first, last and the layers either side of every plausible queue split (run() splits 17 + 13 today)
-    layers = sorted({0, 1, b // 2 - 1, b // 2, (4 * b + 3) // 7 - 1, (4 * b + 3) // 7, b - 2, b - 1})
-    budget = run_case(ob, pie_mod, 32768, 6, T32, 1 << 24, 1 << 12, 2, 13004, 3, 30, b, 2024, layers)
+    budget = run_case(ob, pie_mod, 32768, 6, T32, 1 << 24, 1 << 12, 2, 13004, 3, 30, b, 2024, range(b))   # all 30 bin layers
     assert budget > 0
 
 

@@ -81,6 +81,76 @@ def test_gather_matches_unsharded(world, b):
     assert max(hi - lo for lo, hi in slices) - min(hi - lo for lo, hi in slices) <= 1
 
 
+def _worker_queries(rank, world, port, b, q):
+    """the sharded server's step on CPU: rank 0 alone knows the query; QueryBroadcast hands it to every rank, every rank
+    evaluates its bin layers (the oracle stands in for the GPU), the results are gathered to rank 0"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nested_hashing_psi_amd import shard
+        from oracle import binding as ob
+        N, L, t, K, E = 1024, 2, 65537, 2, 3
+        o = ob.Oracle(N, L, t)
+        rng = np.random.default_rng(7)   # database and key: the same on every rank (loaded once per session)
+
+        def rl(r_, shape):
+            out = np.zeros(shape + (L, N), dtype=np.uint64)
+            for i in range(L):
+                out[..., i, :] = r_.integers(0, int(o.q[i]), shape + (N,), dtype=np.uint64)
+            return out
+
+        db, masks, evk = rl(rng, (K, b, E)), rl(rng, (b,)), rl(rng, (L, 2))
+        lo, hi = shard.bin_slice(b, rank, world)
+        split = K * E * 2 * L * N
+        qb = shard.QueryBroadcast(split + 2 * L * N, "cpu", src=0, kind="broadcast")
+        qrng = np.random.default_rng(1000 + rank)   # rank 0's stream is the only one that is used
+        ok = True
+        for i in range(3):
+            want = None
+            if rank == 0:
+                idx, minus = rl(qrng, (K, E, 2)), rl(qrng, (2,))
+                qb.set_query_host(torch.from_numpy(np.concatenate([idx.reshape(-1), minus.reshape(-1)]).view(np.int64)))
+                want = o.pie_run(idx, minus, db, masks, evk).reshape(b, 2 * L * N).view(np.int64)
+            s = i & 1
+            qb.step(s)
+            flat = qb.ready(s).numpy().view(np.uint64)
+            idx_r = flat[:split].reshape(K, E, 2, L, N)
+            minus_r = flat[split:split + 2 * L * N].reshape(2, L, N)
+            local = np.zeros((0, 2, L, N), dtype=np.uint64)
+            if hi > lo:
+                local = o.pie_run(idx_r, minus_r, np.ascontiguousarray(db[:, lo:hi]), np.ascontiguousarray(masks[lo:hi]), evk)
+            local_t = torch.from_numpy(local.reshape(hi - lo, 2 * L * N).view(np.int64))
+            out0, work = shard.gather_bins_to(local_t, b, world, dst=0, async_op=True)
+            if work is not None:
+                work.wait()
+            if rank == 0:
+                bmax = shard.max_bins(b, world)
+                rows = [out0[r * bmax: r * bmax + (shard.bin_slice(b, r, world)[1] - shard.bin_slice(b, r, world)[0])] for r in range(world)]
+                ok = ok and bool((torch.cat(rows).numpy() == want).all())
+        q.put((rank, ok, (lo, hi)))
+    except Exception as e:  # report instead of hanging the parent on q.get
+        import traceback
+        q.put((rank, False, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,b", [(2, 5), (4, 6)])
+def test_query_distribution_then_gather(world, b):
+    """three consecutive, different queries that only rank 0 knows"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_queries, args=(r, world, port, b, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+
+
 def test_bin_slices_partition():
     from nested_hashing_psi_amd import shard
     for b in (1, 7, 14, 30, 40):

@@ -1,7 +1,10 @@
 """BASELINE config C4 on the hardware available to the tests: the bin layers of one database split over several ranks,
-every rank evaluating its slice with the real library on the GPU (not the oracle), results gathered to rank 0 through
-shard.ResultGather -- the double-buffered run_into / join / gather sequence bench.py times -- and compared, bit for bit,
-with one handle evaluating all bin layers.  One MI355X is visible to the tests, so the ranks share it and the
+every rank evaluating its slice with the real library on the GPU (not the oracle), the query known to rank 0 only and
+distributed inside every step (shard.QueryBroadcast), results gathered to rank 0 through shard.ResultGather -- the
+double-buffered distribute / run_into / join / gather sequence bench.py times.  The small-ring tests compare, bit for bit,
+with one handle evaluating all bin layers; the C4 tests at the end run BASELINE's real shape (N=16384, 4 primes, |S|=2^20,
+K=2, E=14, b=14) with every rank building its slice from the raw server set (piehip_build_db_bins) and compare with the
+ORACLE's run() on all 14 bin layers.  One MI355X is visible to the tests, so the ranks share it and the
 collective runs over `gloo` (RCCL refuses two ranks on one device); a one-rank RCCL group covers the device-tensor path.
 Consecutive queries differ, so a gather that read a buffer too early or a run that overwrote it too soon shows up as a
 mismatch."""
@@ -49,6 +52,8 @@ def _worker(rank, world, port, backend, b, nq, q, nslots=1):
         cc = pie.PieContext(N, L, t, device=0, stream=stream.cuda_stream)
         db, masks, evk = rl((K, b, E), cc.q), rl((b,), cc.q), rl((L, 2), cc.q)
         queries = [(rl((K, E, 2), cc.q), rl((2,), cc.q)) for _ in range(nq)]
+        if rank != 0:
+            queries = [None] * nq     # only rank 0 (the rank that talks to the client) knows the queries
         cc.load_relin_key(evk)
         lo, hi = shard.bin_slice(b, rank, world)
         op = None
@@ -62,19 +67,17 @@ def _worker(rank, world, port, backend, b, nq, q, nslots=1):
             st_ = stream if s_ == 0 else torch.cuda.Stream(device)
             cc_ = cc if s_ == 0 else pie.PieContext(N, L, t, device=0, stream=st_.cuda_stream)
             op_ = op if s_ == 0 else (pie.BatchedFHEHIPPIE(cc_, attachTo=op) if op is not None else None)
-            slots.append(dict(cc=cc_, op=op_, stream=st_,
-                              d_idx=torch.zeros((K, E, 2, L, N), dtype=torch.int64, device=device),
-                              d_minus=torch.zeros((2, L, N), dtype=torch.int64, device=device),
-                              rg=shard.ResultGather(op_, b, hi - lo, ct_words, device, st_, kind="gather")))
-        got = []
-        for i, (idx, minus) in enumerate(queries):
+            q_split = K * E * 2 * L * N
+            qb = shard.QueryBroadcast(q_split + 2 * L * N, device, src=0, kind="broadcast")
+            slots.append(dict(cc=cc_, op=op_, stream=st_, qb=qb,
+                              rg=shard.ResultGather(op_, b, hi - lo, ct_words, device, st_, kind="gather", query=qb, query_split=q_split)))
+        got, keep = [], []
+        for i, query in enumerate(queries):
             sl = slots[i % nslots]
-            with torch.cuda.stream(sl["stream"]):   # the slot's next query overwrites its input arrays in stream order
-                sl["d_idx"].copy_(torch.from_numpy(idx.view(np.int64)), non_blocking=False)
-                sl["d_minus"].copy_(torch.from_numpy(minus.view(np.int64)), non_blocking=False)
-            if sl["op"] is not None:
-                sl["op"].setIndexDevice(sl["d_idx"].data_ptr())
-                sl["op"].setMinusCompareElementDevice(sl["d_minus"].data_ptr())
+            if rank == 0:   # the query in page-locked host memory, one array per query (the upload is asynchronous)
+                flat = torch.from_numpy(np.concatenate([query[0].reshape(-1), query[1].reshape(-1)]).view(np.int64)).pin_memory()
+                keep.append(flat)
+                sl["qb"].set_query_host(flat)
             got.append((sl, sl["rg"].step()))
         for sl in slots:
             sl["rg"].drain()
@@ -140,3 +143,197 @@ def test_one_rank_rccl_device_gather():
     """the RCCL form of the same sequence (device tensors, asynchronous gather on RCCL's stream), also over three slots"""
     _run(1, "nccl", 6)
     _run(1, "nccl", 6, nq=7, nslots=3)
+
+
+# ---- C4 at its real shape, against the oracle ------------------------------------------------------------------------------
+T32 = 4296540161
+C3 = dict(N=16384, L=4, t=T32, k=2, e=4949, K=2, E=14, b=14, nS=1 << 20, nC=1 << 10)
+SEEDS = dict(hash_seed=987654321, evict_seed=1, shuffle_seed=2, mask_seed=3)
+
+
+def _c3_sets(seed=123456789):
+    rng = np.random.default_rng(seed)
+    items = np.unique(rng.integers(1, C3["t"], C3["nS"] + 2 * C3["nC"] + 8192, dtype=np.uint64))
+    rng.shuffle(items)
+    server = items[:C3["nS"]].copy()
+    ninter = C3["nC"] // 2 + 1
+    clients = []
+    for q_ in range(2):     # two different client sets: their intersections with the server set differ
+        fresh = items[C3["nS"] + q_ * C3["nC"]: C3["nS"] + (q_ + 1) * C3["nC"] - ninter]
+        inter = server[q_ * 4096: q_ * 4096 + ninter]
+        c = np.concatenate([inter, fresh])
+        rng.shuffle(c)
+        clients.append((c, inter))
+    return server, clients
+
+
+def _c3_oracle_side(ob, server, clients):
+    """what only the client / the checker know: keys, the encrypted queries, the oracle's packed database"""
+    N, L, t, k, e, K, E, b = (C3[x] for x in ("N", "L", "t", "k", "e", "K", "E", "b"))
+    o = ob.Oracle(N, L, t)
+    tab = ob.Tabulation(SEEDS["hash_seed"], k + K)
+    tbl = ob.hct_build(tab, server, k, e, K, b, E, evict_seed=SEEDS["evict_seed"])
+    ob.hct_shuffle_bins(tbl, SEEDS["shuffle_seed"])
+    slots = ob.pack_db(tbl)
+    mask_slots = ob.masks(t, b, k * e, SEEDS["mask_seed"])
+    sk = o.keygen(11)
+    evk = o.relin_keygen(sk, 12)
+    queries = []
+    for qi, (client, inter) in enumerate(clients):
+        ctab = ob.client_build(tab, client, k, e, evict_seed=4 + qi)
+        index, minus_v = ob.client_vectors(tab, ctab, K, E)
+        idx = np.stack([o.encrypt_slots(sk, index[h, j], 1000 * qi + 100 + h * E + j) for h in range(K) for j in range(E)]).reshape(K, E, 2, L, N)
+        minus = o.encrypt_slots(sk, minus_v, 1000 * qi + 99)
+        queries.append(dict(idx=idx, minus=minus, ctab=ctab, inter=inter))
+    return o, tbl, slots, mask_slots, sk, evk, queries
+
+
+def _c3_oracle_results(ob, o, slots, mask_slots, evk, query, threads=8):
+    """the oracle's run() on all b bin layers (bin layers are independent: one task each; the C call releases the GIL)"""
+    import concurrent.futures
+    L, N, K, E, b = C3["L"], C3["N"], C3["K"], C3["E"], C3["b"]
+
+    def layer(bn):
+        db = np.stack([o.encode_eval(slots[h, bn, j]) for h in range(K) for j in range(E)]).reshape(K, 1, E, L, N)
+        return o.pie_run(query["idx"], query["minus"], db, o.encode_eval(mask_slots[bn])[None], evk)[0]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=threads) as pool:
+        return np.stack(list(pool.map(layer, range(b))))
+
+
+def _c3_check(ob, o, sk, query, rows, want):
+    """rows == the oracle's ciphertexts, and they decrypt (positive budget) to exactly the 513-item intersection"""
+    k, e, b = C3["k"], C3["e"], C3["b"]
+    assert rows.shape == want.shape and (rows == want).all(), "gathered result differs from the oracle"
+    dec = []
+    for bn in range(b):
+        d, bud = o.decrypt_slots(sk, rows[bn], k * e)
+        assert bud > 0
+        dec.append(d)
+    found = ob.client_scan(query["ctab"], np.stack(dec))
+    assert len(found) == C3["nC"] // 2 + 1
+    assert sorted(int(v) for v in found) == sorted(int(v) for v in query["inter"])
+
+
+def _c4_worker(rank, world, port, q, nslots):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    try:
+        device = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from nested_hashing_psi_amd import pie, shard
+        N, L, t, k, e, K, E, b = (C3[x] for x in ("N", "L", "t", "k", "e", "K", "E", "b"))
+        server, clients = _c3_sets()          # the server set is every rank's; the queries are rank 0's
+        ct_words = 2 * L * N
+        side = None
+        evk_t = torch.zeros((L, 2, L, N), dtype=torch.int64)
+        if rank == 0:
+            from oracle import binding as ob
+            ob.build()
+            side = _c3_oracle_side(ob, server, clients)
+            evk_t = torch.from_numpy(side[5].view(np.int64)).clone()
+        dist.broadcast(evk_t, src=0)          # the EvalMult key reaches the server once per session (BatchedFHEPSIServer.cpp:49)
+        stream = torch.cuda.Stream(device)
+        cc = pie.PieContext(N, L, t, device=0, stream=stream.cuda_stream)
+        cc.load_relin_key(evk_t.numpy().view(np.uint64))
+        lo, hi = shard.bin_slice(b, rank, world)
+        # the offline phase on every rank: the whole table is hashed and shuffled, this rank packs its bin layers only
+        op = pie.BatchedFHEHIPPIE(cc, serverSet=server, hashParams=dict(k=k, e=e, K=K, b=b, E=E, **SEEDS), binSlice=(lo, hi))
+        ok, detail = True, ""
+        if rank == 0 and not (op.hashTable() == side[1]).all():
+            ok, detail = False, "hash table differs from the oracle's; "
+        q_split = K * E * 2 * L * N
+        slots = []
+        for s_ in range(nslots):
+            st_ = stream if s_ == 0 else torch.cuda.Stream(device)
+            cc_ = cc if s_ == 0 else pie.PieContext(N, L, t, device=0, stream=st_.cuda_stream)
+            op_ = op if s_ == 0 else pie.BatchedFHEHIPPIE(cc_, attachTo=op)
+            qb = shard.QueryBroadcast(q_split + ct_words, device, src=0, kind="broadcast")
+            slots.append(dict(cc=cc_, qb=qb, rg=shard.ResultGather(op_, b, hi - lo, ct_words, device, st_, kind="gather", query=qb,
+                                                                   query_split=q_split)))
+        nq = 2 * nslots + 1                   # every slot uses both of its buffer sets; consecutive queries differ
+        got, keep = [], []
+        for i in range(nq):
+            sl = slots[i % nslots]
+            if rank == 0:
+                qy = side[6][i % 2]
+                flat = torch.from_numpy(np.concatenate([qy["idx"].reshape(-1), qy["minus"].reshape(-1)]).view(np.int64)).pin_memory()
+                keep.append(flat)
+                sl["qb"].set_query_host(flat)
+            got.append((sl, sl["rg"].step()))
+        for sl in slots:
+            sl["rg"].drain()
+        torch.cuda.synchronize(device)
+        if rank == 0:
+            from oracle import binding as ob
+            o, tbl, oslots, mask_slots, sk, evk, queries = side
+            want = [_c3_oracle_results(ob, o, oslots, mask_slots, evk, qy) for qy in queries]
+            for i in range(max(0, nq - 2 * nslots), nq):    # the last two queries of every slot are still in its buffer sets
+                rows = got[i][0]["rg"].rows(got[i][1]).cpu().numpy().view(np.uint64).reshape(b, 2, L, N)
+                try:
+                    _c3_check(ob, o, sk, queries[i % 2], rows, want[i % 2])
+                except AssertionError as exc:
+                    ok = False
+                    detail += "query %d: %s; " % (i, exc)
+        for sl in reversed(slots):
+            sl["cc"].close()
+        q.put((rank, ok, detail))
+    except Exception as e_:  # report instead of hanging the parent on q.get
+        import traceback
+        q.put((rank, False, repr(e_) + traceback.format_exc()))
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+
+
+@pytest.mark.parametrize("world", [2, 4, 6])
+def test_c4_real_shape_against_the_oracle(world):
+    """BASELINE config C4 (C3's 14 bin layers over `world` ranks: 7+7, 3+4+3+4, 2+2+3+2+2+3), three query slots per rank, real
+    secret-key encrypted queries that only rank 0 holds, every rank's database slice built by piehip_build_db_bins from the
+    raw server set: rank 0's gathered rows equal the oracle's run() on all 14 layers and decrypt to the 513-item
+    intersection.  The ranks share the one GPU of the test box and talk over gloo; six processes is what the box admits on
+    one card (8 slices: test_c4_eight_bin_slices_in_one_process)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c4_worker, args=(r, world, port, q, 3)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    assert all(ok for _, ok, _ in res), res
+
+
+def test_c4_eight_bin_slices_in_one_process(ob, pie_mod):
+    """the 8-GPU partition of C3 (14 layers -> 1,2,2,2,1,2,2,2) as eight handles of one process, each built from the raw server
+    set with its bin slice; the concatenated result lists equal the oracle's run() and decrypt to the intersection; the
+    hash table every handle holds equals the oracle's"""
+    from nested_hashing_psi_amd import shard
+    pie = pie_mod
+    N, L, t, k, e, K, E, b = (C3[x] for x in ("N", "L", "t", "k", "e", "K", "E", "b"))
+    server, clients = _c3_sets()
+    o, tbl, oslots, mask_slots, sk, evk, queries = _c3_oracle_side(ob, server, clients[:1])
+    rows = np.zeros((b, 2, L, N), dtype=np.uint64)
+    sizes = []
+    for r in range(8):
+        lo, hi = shard.bin_slice(b, r, 8)
+        sizes.append(hi - lo)
+        cc = pie.PieContext(N, L, t)
+        cc.load_relin_key(evk)
+        op = pie.BatchedFHEHIPPIE(cc, serverSet=server, hashParams=dict(k=k, e=e, K=K, b=b, E=E, **SEEDS), binSlice=(lo, hi))
+        if r in (0, 7):
+            assert (op.hashTable() == tbl).all()
+        op.setMinusCompareElement(queries[0]["minus"])
+        op.setIndex(queries[0]["idx"])
+        op.run()
+        rows[lo:hi] = op.getResultList()
+        cc.close()
+    assert sorted(sizes) == [1, 1, 2, 2, 2, 2, 2, 2]
+    _c3_check(ob, o, sk, queries[0], rows, _c3_oracle_results(ob, o, oslots, mask_slots, evk, queries[0]))
