@@ -785,7 +785,10 @@ def main():
             line["projected_strong_scaling"] = projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, max(20, args.steps // 4),
                                                                         max(5, args.warmup // 2))
         if not args.no_e2e and world == 1:
-            line["e2e_psi"] = e2e_psi(cfg, pie, cc, lambda: torch.cuda.synchronize(device))
+            # a context of its own: the timed one owns the key and database its query slots are attached to (it refuses reloads)
+            cc_e2e = pie.PieContext(N, L, t, device=local_rank, stream=torch.cuda.Stream(device).cuda_stream)
+            line["e2e_psi"] = e2e_psi(cfg, pie, cc_e2e, lambda: torch.cuda.synchronize(device))
+            cc_e2e.close()
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, max_threads=max(1, args.cpu_threads))
             line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]

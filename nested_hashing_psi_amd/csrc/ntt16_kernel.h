@@ -117,6 +117,21 @@ __device__ __forceinline__ u64 uniform_addr(const void *p)  // (uniform integer 
     return ((u64)hi << 32) | lo;
 }
 
+// x in [0, 2m) -> [0, m) with the NEGATED modulus (2^64 - m): t = x - m as one v_lshl_add_u64, then a select on the sign of t
+// (v_ashrrev_i32 + two v_bfi_b32): 4 instructions where hipcc's `x >= m ? x - m : x` is compare + subtract pair + two
+// v_cndmask_b32 through VCC with its wait states.
+__device__ __forceinline__ u64 csub_neg(u64 x, u64 negm)
+{
+    const u64 t = x + negm;
+    u32 lo, hi, k;
+    asm("v_ashrrev_i32 %[k], 31, %[th]\n\t"
+        "v_bfi_b32 %[lo], %[k], %[xl], %[tl]\n\t"
+        "v_bfi_b32 %[hi], %[k], %[xh], %[th]"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [k] "=&v"(k)
+        : [xl] "v"((u32)x), [xh] "v"((u32)(x >> 32)), [tl] "v"((u32)t), [th] "v"((u32)(t >> 32)));
+    return ((u64)hi << 32) | lo;
+}
+
 // DS operations of one wave execute in issue order: a hand-off inside the wave only needs the compiler kept from
 // moving the reads above the writes
 __device__ __forceinline__ void wave_sync()
@@ -271,11 +286,15 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
                 const u32 LL = a.lift_L, li = __builtin_amdgcn_readfirstlane((limb / LL) % LL), lj = __builtin_amdgcn_readfirstlane(limb % LL);
                 const u64 *src = a.lift_src + (size_t)(limb / (LL * LL)) * a.lift_stride + (size_t)li * a.N;
                 const u64 qh = dcs->mod[li].q / 2, qq = dcs->qi_modqj[li][lj];
+                const u64 nq1 = 0 - q, nqh1 = 0 - (qh + 1);
                 auto lift1 = [&](u64 v) -> u64 {
-                    u64 r = v >= q ? v - q : v;
-                    const u64 c = v > qh ? qq : 0;
-                    r = r >= c ? r - c : r + q - c;
-                    return r;
+                    const u64 r = csub_neg(v, nq1);               // v mod q_j
+                    // centred correction: subtract q_i mod q_j when v > q_i / 2 (mask from the sign of v - (qh + 1))
+                    const u32 neg = (u32)((int32_t)((v + nqh1) >> 32) >> 31);    // ~0 when v <= qh
+                    const u64 c = qq & ~(((u64)neg << 32) | neg);
+                    const u64 d = r - c;                           // in (-q, q)
+                    const u32 dn = (u32)((int32_t)(d >> 32) >> 31);              // ~0 when negative
+                    return d + (q & (((u64)dn << 32) | dn));
                 };
                 if (a.s0 == 1) {
                     // two folded slices per limb: the outermost stage (u, v) -> (u + v psi^{N/2}, u - v psi^{N/2}) is one more
@@ -420,12 +439,8 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
             for (int j = 0; j < 8; j++) {
                 u64 r0 = x[2 * j], r1 = x[2 * j + 1];
                 if (!lazy) {
-                    r0 = r0 >= q4 ? r0 - q4 : r0;
-                    r1 = r1 >= q4 ? r1 - q4 : r1;
-                    r0 = r0 >= q2 ? r0 - q2 : r0;
-                    r1 = r1 >= q2 ? r1 - q2 : r1;
-                    r0 = r0 >= q ? r0 - q : r0;
-                    r1 = r1 >= q ? r1 - q : r1;
+                    r0 = csub_neg(csub_neg(csub_neg(r0, 0 - q4), 0 - q2), 0 - q);
+                    r1 = csub_neg(csub_neg(csub_neg(r1, 0 - q4), 0 - q2), 0 - q);
                 }
                 u64x2 v;
                 v.x = r0;
@@ -572,14 +587,11 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
                     v.x = x[2 * r];
                     v.y = x[2 * r + 1];
                 } else if (a.s0 == 0) {
-                    v.x = mul_shoup(x[2 * r], n_inv, n_inv_sh, q);
-                    v.y = mul_shoup(x[2 * r + 1], n_inv, n_inv_sh, q);
+                    v.x = csub_neg(mul_shoup_lazy(x[2 * r], n_inv, n_inv_sh, q), 0 - q);
+                    v.y = csub_neg(mul_shoup_lazy(x[2 * r + 1], n_inv, n_inv_sh, q), 0 - q);
                 } else {  // split transform: the global-memory stages expect canonical residues
-                    u64 r0 = x[2 * r], r1 = x[2 * r + 1];
-                    r0 = r0 >= q2 ? r0 - q2 : r0;
-                    r1 = r1 >= q2 ? r1 - q2 : r1;
-                    v.x = r0 >= q ? r0 - q : r0;
-                    v.y = r1 >= q ? r1 - q : r1;
+                    v.x = csub_neg(csub_neg(x[2 * r], 0 - q2), 0 - q);
+                    v.y = csub_neg(csub_neg(x[2 * r + 1], 0 - q2), 0 - q);
                 }
                 *reinterpret_cast<u64x2 *>(g + 1024 * r + voff) = v;
             }

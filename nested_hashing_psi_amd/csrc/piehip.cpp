@@ -1351,6 +1351,12 @@ int piehip_host_buffers(piehip_handle h, uint64_t **idx, uint64_t **minus, uint6
     if (!h->pin_res) HIPCHK(hipHostMalloc((void **)&h->pin_res, rw * sizeof(u64), hipHostMallocDefault));
     h->pin_idx_words = iw;
     h->pin_res_words = rw;
+    // whoever asks for the staging arrays is about to run queries from host memory: create the copy queue, its events and the
+    // run queues now (the offline phase), not inside the first timed query
+    int rc = host_path_setup(h);
+    if (rc) return rc;
+    const u32 ng = run_queue_count(h);
+    if (ng > 1 && (rc = ensure_run_queues(h, ng))) return rc;
     if (idx) *idx = h->pin_idx;
     if (minus) *minus = h->pin_minus;
     if (results) *results = h->pin_res;

@@ -291,13 +291,13 @@ def _c4_worker(rank, world, port, q, nslots):
             pass
 
 
-@pytest.mark.parametrize("world", [2, 4, 6])
+@pytest.mark.parametrize("world", [2, 4, 5])
 def test_c4_real_shape_against_the_oracle(world):
-    """BASELINE config C4 (C3's 14 bin layers over `world` ranks: 7+7, 3+4+3+4, 2+2+3+2+2+3), three query slots per rank, real
+    """BASELINE config C4 (C3's 14 bin layers over `world` ranks: 7+7, 3+4+3+4, 2+3+3+3+3), three query slots per rank, real
     secret-key encrypted queries that only rank 0 holds, every rank's database slice built by piehip_build_db_bins from the
     raw server set: rank 0's gathered rows equal the oracle's run() on all 14 layers and decrypt to the 513-item
-    intersection.  The ranks share the one GPU of the test box and talk over gloo; six processes is what the box admits on
-    one card (8 slices: test_c4_eight_bin_slices_in_one_process)."""
+    intersection.  The ranks share the one GPU of the test box and talk over gloo; the box admits six processes on one card
+    (five ranks + this test runner; 8 slices: test_c4_eight_bin_slices_in_one_process)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -4,7 +4,8 @@ gfx950 instruction blocks (the generator can interleave NB independent butterfli
 
 Issue costs on gfx950 (tools/microbench_ops.hip, cycles per wave64 instruction per SIMD with 2+ waves): every VOP3 instruction --
 v_mad_u64_u32, v_lshl_add_u64, v_lshrrev_b64, v_bfi_b32, v_mul_lo/hi_u32 alike -- 4.1-4.3; 32-bit VOP1/VOP2 2.0-2.5; a wave
-alone on its SIMD 4+ for everything.  A forward block is 9 + 7 VOP3 and 5 VOP2 instructions = ~78 cycles.
+alone on its SIMD 4+ for everything; a 2-cycle instruction that follows a 4-cycle one costs 4 itself (tools/microbench_operands.hip), so
+the VOP1/VOP2 instructions are grouped.  Forward block 21 instructions, inverse 22 (its last product is written straight to the output).
 
     python tools/gen_ntt16_bfly.py          (rewrites the .inc; the output is committed)
 
@@ -21,9 +22,9 @@ NREG = {False: 11, True: 13}  # fixed VGPRs per stream: forward (CT), inverse (G
 
 class Regs:
     """Fixed registers of stream i.  Lifetimes allow these overlays (see the instruction lists):
-    both: M over X (the mask is computed after the last use of 2 bh), U over T (the select / t writes in place)
+    both: U over T (the select / t writes in place); the sign mask in QE's low register until qe is written
     CT:   N over CR (cr is dead once qe exists), T6 over QE (computed after the last use of qe)
-    GS:   N and the masked 4q over CR, the early a + 4q + 1 over QE (dead before qe is written), D extra"""
+    GS:   N over CR (~b is dead before m1), the early a + 4q + 1 over QE, the masked 4q over D (d is dead by then)"""
     def __init__(self, i, gs):
         n = NREG[gs]
         self.n = n
@@ -57,19 +58,22 @@ def ct_stream(i):
     r = Regs(i, False)
     o = lambda name: "%%[%s%d]" % (name, i)
     bl, bh = o("bl"), o("bh")
+    m = r.QE  # the sign mask lives in qe's low register until qe is written (the selects consume it before that)
     return [
         "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.CR), bl, o("sh")),                  # m1 = bl sh
         "v_lshl_add_u64 %s, %s, 0, %%[nq4]" % (p(r.T), o("a")),                       # t = a - 4q
-        "v_lshlrev_b32 %s, 1, %s" % (v(r.X), bh),                                     # 2 bh
         "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.CR), bh, o("sl"), p(r.CR)),        # cr = bh sl + m1
         "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.ACC), bl, o("wl")),                 # acc = bl wl
+        # the 2-cycle instructions sit next to each other: one that follows a 4-cycle instruction costs 4 itself
+        # (profiles/r03/microbench_operands.txt, "mad + v_not alternating")
+        "v_lshlrev_b32 %s, 1, %s" % (v(r.X), bh),                                     # 2 bh
+        "v_ashrrev_i32 %s, 31, %s" % (v(m), v(r.T + 1)),                              # all ones iff t < 0
+        "v_bfi_b32 %s, %s, %s, %s" % (v(r.U), v(m), o("al"), v(r.T)),                 # u = t < 0 ? a : t   (in place)
+        "v_bfi_b32 %s, %s, %s, %s" % (v(r.U + 1), v(m), o("ah"), v(r.T + 1)),
         "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.C), bl, o("wh")),                   # c = bl wh
         "v_lshrrev_b64 %s, 31, %s" % (p(r.CR), p(r.CR)),
         "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.C), bh, o("wl"), p(r.C)),          # c += bh wl
         "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.QE), v(r.X), o("sh"), p(r.CR)),    # qe = 2 bh sh + (cr >> 31)
-        "v_ashrrev_i32 %s, 31, %s" % (v(r.M), v(r.T + 1)),                            # all ones iff t < 0   (over 2 bh)
-        "v_bfi_b32 %s, %s, %s, %s" % (v(r.U), v(r.M), o("al"), v(r.T)),               # u = t < 0 ? a : t   (in place)
-        "v_bfi_b32 %s, %s, %s, %s" % (v(r.U + 1), v(r.M), o("ah"), v(r.T + 1)),
         "v_mad_u64_u32 %s, vcc, %s, %%[nql], %s" % (p(r.ACC), v(r.QE), p(r.ACC)),     # acc += qe_lo nq_lo
         "v_mad_u64_u32 %s, vcc, %s, %%[nqh], %s" % (p(r.C), v(r.QE), p(r.C)),         # c += qe_lo nq_hi
         "v_mad_u64_u32 %s, vcc, %s, %%[nql], %s" % (p(r.C), v(r.QE + 1), p(r.C)),     # c += qe_hi nq_lo
@@ -86,6 +90,7 @@ def gs_stream(i):
     r = Regs(i, True)
     o = lambda name: "%%[%s%d]" % (name, i)
     dl, dh = v(r.D), v(r.D + 1)
+    m = r.T6  # sign mask: in the register of a + 4q + 1 (dead once d exists), until qe is written
     return [
         "v_not_b32 %s, %s" % (v(r.N), o("bl")),
         "v_not_b32 %s, %s" % (v(r.N + 1), o("bh")),
@@ -93,23 +98,23 @@ def gs_stream(i):
         "v_lshl_add_u64 %s, %s, 0, %s" % (p(r.U), o("a"), o("b")),                    # s = a + b
         "v_lshl_add_u64 %s, %s, 0, %s" % (p(r.D), p(r.T6), p(r.N)),                   # d = a - b + 4q
         "v_lshl_add_u64 %s, %s, 0, %%[nq4]" % (p(r.T), p(r.U)),                       # t = s - 4q   (in place)
-        "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.CR), dl, o("sh")),
-        "v_lshlrev_b32 %s, 1, %s" % (v(r.X), dh),
-        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.CR), dh, o("sl"), p(r.CR)),
         "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.ACC), dl, o("wl")),
         "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.C), dl, o("wh")),
-        "v_lshrrev_b64 %s, 31, %s" % (p(r.CR), p(r.CR)),
+        "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.CR), dl, o("sh")),                  # (over ~b, dead)
+        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.CR), dh, o("sl"), p(r.CR)),
         "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.C), dh, o("wl"), p(r.C)),
-        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.QE), v(r.X), o("sh"), p(r.CR)),
-        "v_ashrrev_i32 %s, 31, %s" % (v(r.M), v(r.T + 1)),
-        "v_and_b32 %s, %%[q4l], %s" % (v(r.CR), v(r.M)),                              # 4q under the mask   (over cr, dead here)
-        "v_and_b32 %s, %%[q4h], %s" % (v(r.CR + 1), v(r.M)),
-        "v_mad_u64_u32 %s, vcc, %s, %%[nql], %s" % (p(r.ACC), v(r.QE), p(r.ACC)),
-        "v_lshl_add_u64 %s, %s, 0, %s" % (o("ao"), p(r.T), p(r.CR)),                  # a' = t < 0 ? s : t
+        # four 2-cycle instructions in a row (see ct_stream); d is dead after the first of them and takes the masked 4q
+        "v_lshlrev_b32 %s, 1, %s" % (v(r.X), dh),
+        "v_ashrrev_i32 %s, 31, %s" % (v(m), v(r.T + 1)),
+        "v_and_b32 %s, %%[q4l], %s" % (dl, v(m)),                                     # 4q where t < 0
+        "v_and_b32 %s, %%[q4h], %s" % (dh, v(m)),
+        "v_lshrrev_b64 %s, 31, %s" % (p(r.CR), p(r.CR)),
+        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.QE), v(r.X), o("sh"), p(r.CR)),    # the last read of a per-lane twiddle
         "v_mad_u64_u32 %s, vcc, %s, %%[nqh], %s" % (p(r.C), v(r.QE), p(r.C)),
         "v_mad_u64_u32 %s, vcc, %s, %%[nql], %s" % (p(r.C), v(r.QE + 1), p(r.C)),
-        "v_add_u32 %s, %s, %s" % (v(r.ACC + 1), v(r.ACC + 1), v(r.C)),
-        "v_lshl_add_u64 %s, %s, 0, 0" % (o("bo"), p(r.ACC)),                          # b' = d w
+        "v_add_u32 %s, %s, %s" % (v(r.ACC + 1), v(r.ACC + 1), v(r.C)),                # dl wl + (c << 32)
+        "v_lshl_add_u64 %s, %s, 0, %s" % (o("ao"), p(r.T), p(r.D)),                   # a' = t < 0 ? s : t
+        "v_mad_u64_u32 %s, vcc, %s, %%[nql], %s" % (o("bo"), v(r.QE), p(r.ACC)),      # b' = d w: the last product lands in the output
     ]
 
 
