@@ -295,6 +295,228 @@ __device__ __forceinline__ u64 reduce123_u(U128 z, const Mod &m, u64 negq, u64 n
     return csub_u(csub_u(z.lo - qhat * m.q, neg2q), negq);
 }
 
+// ---- constant-operand modular products as instruction blocks (every modulus < 2^60) ---------------------------------------------
+// A mixed VALU stream issues one instruction per ~4 cycles per wave on gfx950 whatever the instruction (a 2-cycle VOP1/VOP2
+// that follows a 4-cycle VOP3 costs 4: profiles/r03/microbench_operands.txt), so these kernels are bound by their instruction
+// COUNT.  hipcc spends 28 instructions on a Shoup product with a wave-uniform constant (an exact __umul64hi with six register
+// moves, three 64-bit low products through v_mul_lo_u32 + v_add3_u32, a subtraction through VCC with its wait state); the NTT
+// butterfly's formulation does it in 12 -- quotient estimate from the 63-bit constant floor(w 2^63 / q) with three multiplier
+// operations (error <= 3), remainder a w + qe (2^64 - q) on two v_mad_u64_u32 chains -- plus two sign-mask subtractions for a
+// canonical result.  Temporaries whose halves are needed live in fixed registers v84-v95 (an asm operand cannot name the
+// halves of a 64-bit pair); constants are SGPR operands, one per instruction (constant-bus limit of VOP3 on gfx9).
+#define PIE_ASM_CLOB "vcc", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95"
+// a < 2^63, w < q < 2^60: v[88:89] <- all but the last product of a w mod q + {0..3} q, v[86:87] <- the quotient estimate
+#define PIE_SHOUP63_HEAD                                        \
+    "v_mad_u64_u32 v[84:85], vcc, %[al], %[sh], 0\n\t"          \
+    "v_mad_u64_u32 v[88:89], vcc, %[al], %[wl], 0\n\t"          \
+    "v_mad_u64_u32 v[84:85], vcc, %[ah], %[sl], v[84:85]\n\t"   \
+    "v_mad_u64_u32 v[90:91], vcc, %[al], %[wh], 0\n\t"          \
+    "v_lshlrev_b32 v94, 1, %[ah]\n\t"                           \
+    "v_mad_u64_u32 v[90:91], vcc, %[ah], %[wl], v[90:91]\n\t"   \
+    "v_lshrrev_b64 v[84:85], 31, v[84:85]\n\t"                  \
+    "v_mad_u64_u32 v[86:87], vcc, v94, %[sh], v[84:85]\n\t"     \
+    "v_mad_u64_u32 v[90:91], vcc, v86, %[nqh], v[90:91]\n\t"    \
+    "v_mad_u64_u32 v[90:91], vcc, v87, %[nql], v[90:91]\n\t"    \
+    "v_add_u32 v89, v89, v90\n\t"
+#define PIE_SHOUP63_IN(a, w, wsh, nq)                                                                                        \
+    [al] "v"((u32)(a)), [ah] "v"((u32)((a) >> 32)), [wl] "s"((u32)(w)), [wh] "s"((u32)((w) >> 32)), [sl] "s"((u32)((wsh) >> 1)), \
+        [sh] "s"((u32)((wsh) >> 33)), [nql] "s"((u32)(nq)), [nqh] "s"((u32)((nq) >> 32))
+// a w mod q + {0,1,2,3} q for a < 2^63 (wsh = floor(w 2^64 / q), nq = 2^64 - q): 12 instructions
+__device__ __forceinline__ u64 shoup63_lazy(u64 a, u64 w, u64 wsh, u64 nq)
+{
+    u64 r;
+    asm(PIE_SHOUP63_HEAD
+        "v_mad_u64_u32 %[r], vcc, v86, %[nql], v[88:89]"
+        : [r] "=v"(r)
+        : PIE_SHOUP63_IN(a, w, wsh, nq)
+        : PIE_ASM_CLOB);
+    return r;
+}
+// ... reduced to [0, q): 20 instructions
+__device__ __forceinline__ u64 shoup63(u64 a, u64 w, u64 wsh, u64 nq)
+{
+    u32 lo, hi;
+    const u64 n2q = 2 * nq;  // 2^64 - 2q
+    asm(PIE_SHOUP63_HEAD
+        "v_mad_u64_u32 v[88:89], vcc, v86, %[nql], v[88:89]\n\t"
+        "v_lshl_add_u64 v[92:93], v[88:89], 0, %[n2q]\n\t"
+        "v_ashrrev_i32 v95, 31, v93\n\t"
+        "v_bfi_b32 v88, v95, v88, v92\n\t"
+        "v_bfi_b32 v89, v95, v89, v93\n\t"
+        "v_lshl_add_u64 v[92:93], v[88:89], 0, %[n1q]\n\t"
+        "v_ashrrev_i32 v95, 31, v93\n\t"
+        "v_bfi_b32 %[lo], v95, v88, v92\n\t"
+        "v_bfi_b32 %[hi], v95, v89, v93"
+        : [lo] "=v"(lo), [hi] "=v"(hi)
+        : PIE_SHOUP63_IN(a, w, wsh, nq), [n2q] "s"(n2q), [n1q] "s"(nq)
+        : PIE_ASM_CLOB);
+    return ((u64)hi << 32) | lo;
+}
+// exact floor(a w / q) and a w mod q for a < q: the estimate is at most 3 short, and each of the two conditional
+// subtractions reports whether it subtracted (64-bit sign masks M: quotient = qe + 3 + 2 M1 + M2).  23 instructions
+__device__ __forceinline__ void divmod63(u64 a, u64 w, u64 wsh, u64 nq, u64 &quot, u64 &rem)
+{
+    u32 lo, hi;
+    u64 qt;
+    const u64 n2q = 2 * nq;
+    asm(PIE_SHOUP63_HEAD
+        "v_mad_u64_u32 v[88:89], vcc, v86, %[nql], v[88:89]\n\t"
+        "v_lshl_add_u64 v[92:93], v[88:89], 0, %[n2q]\n\t"
+        "v_ashrrev_i64 v[84:85], 63, v[92:93]\n\t"
+        "v_bfi_b32 v88, v84, v88, v92\n\t"
+        "v_bfi_b32 v89, v84, v89, v93\n\t"
+        "v_lshl_add_u64 v[86:87], v[84:85], 1, v[86:87]\n\t"
+        "v_lshl_add_u64 v[92:93], v[88:89], 0, %[n1q]\n\t"
+        "v_ashrrev_i64 v[84:85], 63, v[92:93]\n\t"
+        "v_bfi_b32 %[lo], v84, v88, v92\n\t"
+        "v_bfi_b32 %[hi], v84, v89, v93\n\t"
+        "v_lshl_add_u64 v[86:87], v[84:85], 0, v[86:87]\n\t"
+        "v_lshl_add_u64 %[qt], v[86:87], 0, 3"
+        : [lo] "=v"(lo), [hi] "=v"(hi), [qt] "=v"(qt)
+        : PIE_SHOUP63_IN(a, w, wsh, nq), [n2q] "s"(n2q), [n1q] "s"(nq)
+        : PIE_ASM_CLOB);
+    quot = qt;
+    rem = ((u64)hi << 32) | lo;
+}
+// exact floor(a b / 2^64), b wave-uniform: the cross products are summed with the carry kept (VCC is read two instructions
+// after it is written: the wait states a VALU read of a VALU-written VCC needs on gfx950).  8 instructions (hipcc: 11)
+__device__ __forceinline__ u64 mulhi_sb(u64 a, u64 b)
+{
+    u64 r;
+    asm("v_mul_hi_u32 v84, %[al], %[bl]\n\t"
+        "v_mov_b32 v85, 0\n\t"
+        "v_mad_u64_u32 v[86:87], vcc, %[al], %[bh], v[84:85]\n\t"
+        "v_mad_u64_u32 v[86:87], vcc, %[ah], %[bl], v[86:87]\n\t"
+        "v_mad_u64_u32 v[90:91], s[96:97], %[ah], %[bh], 0\n\t"
+        "v_lshrrev_b64 v[88:89], 32, v[86:87]\n\t"
+        "v_addc_co_u32 v89, vcc, 0, v89, vcc\n\t"
+        "v_lshl_add_u64 %[r], v[90:91], 0, v[88:89]"
+        : [r] "=v"(r)
+        : [al] "v"((u32)a), [ah] "v"((u32)(a >> 32)), [bl] "s"((u32)b), [bh] "s"((u32)(b >> 32))
+        : PIE_ASM_CLOB, "s96", "s97");
+    return r;
+}
+// Column accumulator -> residue in one block (2^59 < q < 2^60).  The columns are carry-normalised (c1' = c1 + (c0 >> 30),
+// c2' = c2 + (c1' >> 30)), after which z >> 59 = (c2' << 1) | bit 29 of c1' and the low word of z is three disjoint bit fields;
+// one-word Barrett as reduce123 / reduce124 of modarith.h (same quotient estimate, same remainder), mulhi as mulhi_sb, the
+// remainder z + qhat (2^64 - q) on one v_mad_u64_u32 chain, sign-mask subtractions.  32 instructions (35 with W124) where the
+// compiler's colacc_value + reduce123 take ~65 (128-bit additions through v_cmp / v_cndmask carries, an 11-instruction mulhi).
+// W124: z < 2^124 (eight products), otherwise z < 2^123 (seven).
+template <bool W124>
+__device__ __forceinline__ u64 colacc_reduce(const ColAcc &a, const Mod &m, u64 nq)
+{
+    const u64 mu = (m.r1 << 59) | (m.r0 >> 5);   // floor(2^123 / q)
+    const u64 n2q = 2 * nq, n4q = 4 * nq;
+    u64 r;
+    if (!W124) {
+        asm("v_lshrrev_b64 v[84:85], 30, %[c0]\n\t"
+            "v_lshl_add_u64 v[84:85], v[84:85], 0, %[c1]\n\t"
+            "v_lshrrev_b64 v[86:87], 30, v[84:85]\n\t"
+            "v_lshl_add_u64 v[86:87], v[86:87], 0, %[c2]\n\t"
+            "v_lshlrev_b64 v[88:89], 1, v[86:87]\n\t"
+            "v_bfe_u32 v92, v84, 29, 1\n\t"
+            "v_and_b32 v90, 0x3fffffff, %[c0l]\n\t"
+            "v_bfe_u32 v91, v84, 2, 28\n\t"
+            "v_or_b32 v88, v88, v92\n\t"
+            "v_lshl_or_b32 v90, v84, 30, v90\n\t"
+            "v_lshl_or_b32 v91, v86, 28, v91\n\t"
+            "v_mul_hi_u32 v92, v88, %[mul]\n\t"
+            "v_mov_b32 v93, 0\n\t"
+            "v_mad_u64_u32 v[92:93], vcc, v88, %[muh], v[92:93]\n\t"
+            "v_mad_u64_u32 v[92:93], vcc, v89, %[mul], v[92:93]\n\t"
+            "v_mad_u64_u32 v[94:95], s[96:97], v89, %[muh], 0\n\t"
+            "v_lshrrev_b64 v[92:93], 32, v[92:93]\n\t"
+            "v_addc_co_u32 v93, vcc, 0, v93, vcc\n\t"
+            "v_lshl_add_u64 v[92:93], v[94:95], 0, v[92:93]\n\t"
+            "v_mad_u64_u32 v[94:95], vcc, v92, %[nqh], 0\n\t"
+            "v_mad_u64_u32 v[94:95], vcc, v93, %[nql], v[94:95]\n\t"
+            "v_add_u32 v91, v91, v94\n\t"
+            "v_mad_u64_u32 v[90:91], vcc, v92, %[nql], v[90:91]\n\t"
+            "v_lshl_add_u64 v[84:85], v[90:91], 0, %[n2q]\n\t"
+            "v_ashrrev_i32 v86, 31, v85\n\t"
+            "v_bfi_b32 v90, v86, v90, v84\n\t"
+            "v_bfi_b32 v91, v86, v91, v85\n\t"
+            "v_lshl_add_u64 v[84:85], v[90:91], 0, %[n1q]\n\t"
+            "v_ashrrev_i32 v86, 31, v85\n\t"
+            "v_and_b32 v88, %[ql], v86\n\t"
+            "v_and_b32 v89, %[qh], v86\n\t"
+            "v_lshl_add_u64 %[r], v[84:85], 0, v[88:89]"
+            : [r] "=v"(r)
+            : [c0] "v"(a.c0), [c1] "v"(a.c1), [c2] "v"(a.c2), [c0l] "v"((u32)a.c0), [mul] "s"((u32)mu), [muh] "s"((u32)(mu >> 32)),
+              [nql] "s"((u32)nq), [nqh] "s"((u32)(nq >> 32)), [n2q] "s"(n2q), [n1q] "s"(nq), [ql] "s"((u32)m.q), [qh] "s"((u32)(m.q >> 32))
+            : PIE_ASM_CLOB, "s96", "s97");
+    } else {
+        // z >> 60 = c2' after the normalisation; qhat = 2 floor(zh mu / 2^64); remainder in [0, 7q): one more subtraction
+        asm("v_lshrrev_b64 v[84:85], 30, %[c0]\n\t"
+            "v_lshl_add_u64 v[84:85], v[84:85], 0, %[c1]\n\t"
+            "v_lshrrev_b64 v[88:89], 30, v[84:85]\n\t"
+            "v_lshl_add_u64 v[88:89], v[88:89], 0, %[c2]\n\t"
+            "v_and_b32 v90, 0x3fffffff, %[c0l]\n\t"
+            "v_bfe_u32 v91, v84, 2, 28\n\t"
+            "v_lshl_or_b32 v90, v84, 30, v90\n\t"
+            "v_lshl_or_b32 v91, v88, 28, v91\n\t"
+            "v_mul_hi_u32 v92, v88, %[mul]\n\t"
+            "v_mov_b32 v93, 0\n\t"
+            "v_mad_u64_u32 v[92:93], vcc, v88, %[muh], v[92:93]\n\t"
+            "v_mad_u64_u32 v[92:93], vcc, v89, %[mul], v[92:93]\n\t"
+            "v_mad_u64_u32 v[94:95], s[96:97], v89, %[muh], 0\n\t"
+            "v_lshrrev_b64 v[92:93], 32, v[92:93]\n\t"
+            "v_addc_co_u32 v93, vcc, 0, v93, vcc\n\t"
+            "v_lshl_add_u64 v[92:93], v[94:95], 0, v[92:93]\n\t"
+            "v_lshlrev_b64 v[92:93], 1, v[92:93]\n\t"
+            "v_mad_u64_u32 v[94:95], vcc, v92, %[nqh], 0\n\t"
+            "v_mad_u64_u32 v[94:95], vcc, v93, %[nql], v[94:95]\n\t"
+            "v_add_u32 v91, v91, v94\n\t"
+            "v_mad_u64_u32 v[90:91], vcc, v92, %[nql], v[90:91]\n\t"
+            "v_lshl_add_u64 v[84:85], v[90:91], 0, %[n4q]\n\t"
+            "v_ashrrev_i32 v86, 31, v85\n\t"
+            "v_bfi_b32 v90, v86, v90, v84\n\t"
+            "v_bfi_b32 v91, v86, v91, v85\n\t"
+            "v_lshl_add_u64 v[84:85], v[90:91], 0, %[n2q]\n\t"
+            "v_ashrrev_i32 v86, 31, v85\n\t"
+            "v_bfi_b32 v90, v86, v90, v84\n\t"
+            "v_bfi_b32 v91, v86, v91, v85\n\t"
+            "v_lshl_add_u64 v[84:85], v[90:91], 0, %[n1q]\n\t"
+            "v_ashrrev_i32 v86, 31, v85\n\t"
+            "v_and_b32 v88, %[ql], v86\n\t"
+            "v_and_b32 v89, %[qh], v86\n\t"
+            "v_lshl_add_u64 %[r], v[84:85], 0, v[88:89]"
+            : [r] "=v"(r)
+            : [c0] "v"(a.c0), [c1] "v"(a.c1), [c2] "v"(a.c2), [c0l] "v"((u32)a.c0), [mul] "s"((u32)mu), [muh] "s"((u32)(mu >> 32)),
+              [nql] "s"((u32)nq), [nqh] "s"((u32)(nq >> 32)), [n4q] "s"(n4q), [n2q] "s"(n2q), [n1q] "s"(nq), [ql] "s"((u32)m.q),
+              [qh] "s"((u32)(m.q >> 32))
+            : PIE_ASM_CLOB, "s96", "s97");
+    }
+    return r;
+}
+// a small integer v (< 2^30) times a residue c, into the columns
+__device__ __forceinline__ void colacc_mac_small(ColAcc &a, u32 v, u64 c)
+{
+    const Split30 s = split30(c);
+    a.c0 = mad_u(v, s.lo, a.c0);
+    a.c1 = mad_u(v, s.hi, a.c1);
+}
+
+// the instruction-block forms of the helpers above where every modulus is below 2^60 (ASM), the compiler's otherwise
+template <bool ASM>
+__device__ __forceinline__ u64 mshoup(u64 a, u64 w, u64 wsh, u64 q, u64 negq)
+{
+    return ASM ? shoup63(a, w, wsh, negq) : mul_shoup_u(a, w, wsh, q, negq);
+}
+template <bool ASM>
+__device__ __forceinline__ void mdivmod(u64 a, u64 w, u64 wsh, u64 q, u64 negq, u64 &quot, u64 &rem)
+{
+    if (ASM)
+        divmod63(a, w, wsh, negq, quot, rem);
+    else
+        divmod_shoup_u(a, w, wsh, q, negq, quot, rem);
+}
+template <bool ASM>
+__device__ __forceinline__ u64 mfixfrac(u64 y, const Mod &m)
+{
+    return ASM ? (mulhi_sb(y << m.fshift, m.fconst) >> 3) : fixfrac_u(y, m);
+}
+
 // sum_i y[i] * c[i] as a 128-bit integer.  MAD: carry-free column accumulators on v_mad_u64_u32 (madasm.h; needs all
 // operands < 2^60 and NS <= 8), otherwise 64x64->128 multiplies.
 template <u32 NS, bool MAD>
@@ -317,10 +539,18 @@ __device__ __forceinline__ U128 dot128(const u64 *y, const u64 (&c)[NS])
 template <u32 NS, bool MAD>
 __device__ __forceinline__ u64 crt_out(const u64 *y, const u64 (&hat)[NS], u64 v, u64 prodmod, const Mod &tm, u64 negq, u64 neg2q)
 {
+    if (MAD && NS <= 7) {
+        // MAD implies 2^59 < q < 2^60 for every modulus: up to 7 products plus the small term stay below 2^123; everything
+        // goes through the column accumulator (v <= NS is one more, partial, term) and one reduction block
+        ColAcc a = {0, 0, 0};
+#pragma unroll
+        for (u32 i = 0; i < NS; i++) colacc_mac(a, split30(y[i]), split30(hat[i]));
+        colacc_mac_small(a, (u32)v, tm.q - prodmod);  // - v * prodmod (mod tm)
+        return colacc_reduce<false>(a, tm, negq);
+    }
     U128 acc = dot128<NS, MAD>(y, hat);
     mac128(acc, v, tm.q - prodmod);  // - v * prodmod (mod tm); v <= ns: one Barrett reduction for the whole sum
-    // MAD implies 2^59 < q < 2^60 for every modulus: up to 7 products plus the small terms stay below 2^123
-    return (MAD && NS <= 7) ? reduce123_u(acc, tm, negq, neg2q) : reduce128(acc, tm);
+    return reduce128(acc, tm);
 }
 
 // Outer-stage folding.  For N >= 2^14 the transforms next to these kernels run as two half-size slices per limb
@@ -335,17 +565,17 @@ __device__ __forceinline__ void fold_load(const DevConsts *dc, u32 a, u64 u, u64
     PIE_ITER_FENCE();
     const DcC c = dc_iter(dc);
     const u64 q = c->mod[a].q, nq = neg_u(q);
-    x0 = mul_shoup_u(u + v, c->fold_ia[a], c->fold_ia_sh[a], q, nq);
-    x1 = mul_shoup_u(u + (4 * q - v), c->fold_ib[a], c->fold_ib_sh[a], q, nq);
+    x0 = shoup63(u + v, c->fold_ia[a], c->fold_ia_sh[a], nq);            // (folding implies q < 2^60)
+    x1 = shoup63(u + (4 * q - v), c->fold_ib[a], c->fold_ib_sh[a], nq);
 }
-// u canonical; results in (0, 3q)
+// u canonical; results in (0, 5q)
 __device__ __forceinline__ void fold_store(const DevConsts *dc, u32 a, u64 u, u64 v, u64 &y0, u64 &y1)
 {
     const DcC c = dc_iter(dc);
     const u64 q = c->mod[a].q;
-    const u64 t = mul_shoup_lazy_u(v, c->fold_w[a], c->fold_w_sh[a], q);  // [0, 2q)
+    const u64 t = shoup63_lazy(v, c->fold_w[a], c->fold_w_sh[a], neg_u(q));  // [0, 4q)
     y0 = u + t;
-    y1 = u + (2 * q - t);
+    y1 = u + (4 * q - t);
 }
 
 // The RNS width L is a template parameter: with run-time trip counts hipcc indexes the per-coefficient residue
@@ -371,8 +601,8 @@ __device__ __forceinline__ void expand_core(const DevConsts *dc, const u64 (&x)[
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             out[p][i] = x[p][i];
-            y[p][i] = YIN ? x[p][i] : mul_shoup_u(x[p][i], w, wsh, mi.q, nq);
-            fsum[p] += fixfrac_u(y[p][i], mi);
+            y[p][i] = YIN ? x[p][i] : mshoup<MAD>(x[p][i], w, wsh, mi.q, nq);
+            fsum[p] += mfixfrac<MAD>(y[p][i], mi);
         }
     }
 #pragma unroll
@@ -407,12 +637,12 @@ __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 (&x
         const u64 w = c->qhat_inv[i], wsh = c->qhat_inv_sh[i], pw = c->P_modq[i], pwsh = c->P_modq_sh[i], nq = neg_u(mi.q);
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            y[p][i] = YIN ? x[p][i] : mul_shoup_u(x[p][i], w, wsh, mi.q, nq);
+            y[p][i] = YIN ? x[p][i] : mshoup<MAD>(x[p][i], w, wsh, mi.q, nq);
             // y_i P / q_i = y_i floor(P/q_i) + floor(y_i w_i / q_i) + (y_i w_i mod q_i) / q_i
             u64 fl, z;
-            divmod_shoup_u(y[p][i], pw, pwsh, mi.q, nq, fl, z);
+            mdivmod<MAD>(y[p][i], pw, pwsh, mi.q, nq, fl, z);
             add128(itot[p], U128{fl, 0});
-            fsum[p] += fixfrac_u(z, mi);
+            fsum[p] += mfixfrac<MAD>(z, mi);
         }
     }
     u64 yp[NP][Lp];
@@ -433,12 +663,20 @@ __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 (&x
         const u64 w = c->phat_inv[j], wsh = c->phat_inv_sh[j], nq = neg_u(pj.q), n2q = neg_u(2 * pj.q);
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            U128 acc = dot128<L, MAD>(y[p], col);
-            add128(acc, itot[p]);
-            const u64 r = MAD ? reduce123_u(acc, pj, nq, n2q) : reduce128(acc, pj);  // L <= 7 products + a 64-bit term
+            u64 r;
+            if (MAD) {   // L <= 7 products + the integer parts (< (L + 1) 2^60, in column 0): below 2^123
+                ColAcc a = {itot[p].lo, 0, 0};
+#pragma unroll
+                for (u32 i = 0; i < L; i++) colacc_mac(a, split30(y[p][i]), split30(col[i]));
+                r = colacc_reduce<false>(a, pj, nq);
+            } else {
+                U128 acc = dot128<L, MAD>(y[p], col);
+                add128(acc, itot[p]);
+                r = reduce128(acc, pj);
+            }
             out[p][L + j] = r;
-            yp[p][j] = mul_shoup_u(r, w, wsh, pj.q, nq);
-            fs2[p] += fixfrac_u(yp[p][j], pj);
+            yp[p][j] = mshoup<MAD>(r, w, wsh, pj.q, nq);
+            fs2[p] += mfixfrac<MAD>(yp[p][j], pj);
         }
     }
 #pragma unroll
@@ -477,8 +715,8 @@ __global__ void __launch_bounds__(TPB) expand_kernel(const DevConsts *__restrict
             PIE_ITER_FENCE();
             const DcC c = dc_iter(dc);
             const u64 q = c->mod[i].q, nq = neg_u(q), u = pin[(size_t)i * N], v = pin[(size_t)i * N + H];
-            x[0][i] = mul_shoup_u(u + v, c->fold_iaq[i], c->fold_iaq_sh[i], q, nq);            // u, v in [0, 4q)
-            x[NP - 1][i] = mul_shoup_u(u + (4 * q - v), c->fold_ibq[i], c->fold_ibq_sh[i], q, nq);
+            x[0][i] = shoup63(u + v, c->fold_iaq[i], c->fold_iaq_sh[i], nq);            // u, v in [0, 4q)
+            x[NP - 1][i] = shoup63(u + (4 * q - v), c->fold_ibq[i], c->fold_ibq_sh[i], nq);
         } else if (FOLD) {
             fold_load(dc, i, pin[(size_t)i * N], pin[(size_t)i * N + H], x[0][i], x[NP - 1][i]);
         } else {
@@ -587,11 +825,11 @@ __device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 
         const u64 w = c->qp_hat_inv[L + j], wsh = c->qp_hat_inv_sh[L + j], tw = c->tQ_modp[j], twsh = c->tQ_modp_sh[j], nq = neg_u(pj.q);
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            yp[p][j] = mul_shoup_u(d[p][L + j], w, wsh, pj.q, nq);
+            yp[p][j] = mshoup<MAD>(d[p][L + j], w, wsh, pj.q, nq);
             u64 fl, z;
-            divmod_shoup_u(yp[p][j], tw, twsh, pj.q, nq, fl, z);
+            mdivmod<MAD>(yp[p][j], tw, twsh, pj.q, nq, fl, z);
             add128(itot[p], U128{fl, 0});
-            fsum[p] += fixfrac_u(z, pj);
+            fsum[p] += mfixfrac<MAD>(z, pj);
         }
     }
 #pragma unroll
@@ -607,10 +845,18 @@ __device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 
         const u64 tp = c->tPinv_modq[k], nq = neg_u(qk.q), n2q = neg_u(2 * qk.q);
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            U128 acc = dot128<Lp, MAD>(yp[p], col);
-            mac128(acc, d[p][k], tp);
-            add128(acc, itot[p]);
-            out[p][k] = (MAD && L <= 5) ? reduce123_u(acc, qk, nq, n2q) : reduce128(acc, qk);  // L + 2 products
+            if (MAD && L <= 6) {   // L + 2 products + the integer parts (< (L + 2) 2^60, in column 0)
+                ColAcc a = {itot[p].lo, 0, 0};
+#pragma unroll
+                for (u32 j = 0; j < Lp; j++) colacc_mac(a, split30(yp[p][j]), split30(col[j]));
+                colacc_mac(a, split30(d[p][k]), split30(tp));
+                out[p][k] = colacc_reduce<(L > 5)>(a, qk, nq);
+            } else {
+                U128 acc = dot128<Lp, MAD>(yp[p], col);
+                mac128(acc, d[p][k], tp);
+                add128(acc, itot[p]);
+                out[p][k] = reduce128(acc, qk);
+            }
         }
     }
 }
