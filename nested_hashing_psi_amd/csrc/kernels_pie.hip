@@ -100,6 +100,8 @@ __global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *__restric
 // with seven layers per thread (168 registers, three waves per SIMD), the same with 16-byte lanes and one term ahead, 63 us
 // when it is forced to four waves per SIMD (spills) -- and 35 us for a plain read of the same bytes.
 static const int SA_DEPTH = 4;
+template <bool W124>
+__device__ __forceinline__ u64 colacc_reduce(const ColAcc &a, const Mod &m, u64 nq);  // (instruction block, defined below)
 template <int BPT>
 __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
                                                           const u64 *__restrict__ idx, const u64 *__restrict__ minus,
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
         u64 *po = acc + (((size_t)(beta0 + t) * K + h) * 2) * LN + (size_t)l * N + n;
 #pragma unroll
         for (int c = 0; c < 2; c++)
-            po[(size_t)c * LN] = addmod(reduce124(colacc_value(a[t][c]), m), minus[(size_t)c * LN + (size_t)l * N + n], m.q);
+            po[(size_t)c * LN] = addmod(colacc_reduce<true>(a[t][c], m, 0 - m.q), minus[(size_t)c * LN + (size_t)l * N + n], m.q);
     }
 }
 

@@ -41,13 +41,14 @@ static constexpr u32 TWK_PER_SLICE = 8 * 15 * 16 + 8 * 12 * 64;  // kernel-order
 
 __device__ __forceinline__ u32 phi(u32 e) { return e + 2 * (e >> 5); }
 
-struct Tw {  // {w, floor(w 2^63 / q)} split into 32-bit halves
-    u32 wl, wh, sl, sh;
+struct Tw {  // {w, floor(w 2^63 / q)} split into 32-bit halves; sh2 = 2 sh (sh < 2^31) for the quotient estimate
+    u32 wl, wh, sl, sh, sh2;
 };
 __device__ __forceinline__ Tw make_tw(u64x2 p)
 {
     Tw t;
     t.wl = (u32)p.x, t.wh = (u32)(p.x >> 32), t.sl = (u32)p.y, t.sh = (u32)(p.y >> 32);
+    t.sh2 = t.sh << 1;  // wave-uniform twiddles: a scalar shift; per-lane ones: one shift per twiddle, not per butterfly
     return t;
 }
 
@@ -65,7 +66,7 @@ struct ModC {
 // (derivation in kernels_ntt_fast.hip).  Why assembly blocks (tools/gen_ntt16_bfly.py writes them): hipcc narrows multiplier
 // ops whose high half is dead to v_mul_lo_u32 (half the rate), lowers conditional subtractions to compare + select chains
 // through VCC (a VALU write of VCC or an SGPR needs two wait states before a VALU may read it on gfx950) and pads every short
-// asm statement with s_nop.  21 (forward) / 23 (inverse) instructions per butterfly, 9 of them on the multiplier, 11 / 13
+// asm statement with s_nop.  20-21 (forward) / 21-22 (inverse) instructions per butterfly, 9 of them on the multiplier, 11 / 13
 // fixed scratch registers at the top of the 128-register budget, no VCC reads (carry-outs are discarded into VCC); conditional
 // subtraction x in [0, 2m) -> [0, m) as t = x - m followed by a select on the sign of t (v_bfi / v_and under an
 // arithmetic-shift mask).
@@ -75,31 +76,41 @@ struct ModC {
 
 // forward (Cooley-Tukey): a, b in [0, 8q) -> a' = u + v, b' = u - v + 4q with u = a mod+ 4q in [0, 4q), v = b w in [0, 4q)
 // inverse (Gentleman-Sande): a, b in [0, 4q) -> a' = (a + b) mod+ 4q, b' = (a - b + 4q) w, both in [0, 4q)
-// SC: the twiddles are wave-uniform (SGPR operands)
-template <bool INV, bool SC>
+// SC: the twiddles are wave-uniform (SGPR operands).  H2: the block takes 2 sh as an operand (t.sh2) instead of doubling the
+// high word of the multiplicand itself -- one instruction fewer; worth it where a twiddle serves several butterflies (every
+// wave-uniform one: the doubling is a scalar instruction; per-lane ones of the stages with fewer twiddles than butterflies).
+// The inverse block has that form for wave-uniform twiddles only (tools/gen_ntt16_bfly.py); the inverse kernel does not use
+// it: the extra scalar operands push it into scalar-register spills (measured: 96.2 vs 95.7 us per 2048 slices).
+template <bool INV, bool SC, bool H2 = SC && !INV>
 __device__ __forceinline__ void bfly(u64 &x0, u64 &y0, const Tw &t0, const ModC &m)
 {
     const u64 a0 = x0, b0 = y0;
     u64 ao0, bo0;
     if (INV) {
-        if (SC)
+        if (SC && H2)
+            NTT16_GS1HS();
+        else if (SC)
             NTT16_GS1(NTT16_S);
         else
             NTT16_GS1(NTT16_V);
     } else {
-        if (SC)
+        if (SC && H2)
+            NTT16_CT1H(NTT16_S);
+        else if (SC)
             NTT16_CT1(NTT16_S);
+        else if (H2)
+            NTT16_CT1H(NTT16_V);
         else
             NTT16_CT1(NTT16_V);
     }
     x0 = ao0, y0 = bo0;
 }
 // two butterflies (call sites pair them; one block each: see tools/gen_ntt16_bfly.py on why they are not interleaved)
-template <bool INV, bool SC>
+template <bool INV, bool SC, bool H2 = SC && !INV>
 __device__ __forceinline__ void bfly2(u64 &x0, u64 &y0, const Tw &t0, u64 &x1, u64 &y1, const Tw &t1, const ModC &m)
 {
-    bfly<INV, SC>(x0, y0, t0, m);
-    bfly<INV, SC>(x1, y1, t1, m);
+    bfly<INV, SC, H2>(x0, y0, t0, m);
+    bfly<INV, SC, H2>(x1, y1, t1, m);
 }
 // m-th index in [0, 16) whose bit `d` (a power of two) is clear
 __device__ __forceinline__ constexpr int bfly_lo(int m, int d) { return ((m & ~(d - 1)) << 1) | (m & (d - 1)); }
@@ -383,14 +394,14 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
             {
                 const Tw t = make_tw(t7[0]);
 #pragma unroll
-                for (int k = 0; k < 8; k += 2) bfly2<false, false>(x[k], x[k + 8], t, x[k + 1], x[k + 9], t, mc);
+                for (int k = 0; k < 8; k += 2) bfly2<false, false, true>(x[k], x[k + 8], t, x[k + 1], x[k + 9], t, mc);
             }
             NTT16_LOAD3H(t10, 3, 0);
             NTT16_FENCE();
 #pragma unroll
             for (int mm = 0; mm < 8; mm += 2) {
                 const int k0 = bfly_lo(mm, 4), k1 = bfly_lo(mm + 1, 4);
-                bfly2<false, false>(x[k0], x[k0 + 4], make_tw(t8[k0 >> 3]), x[k1], x[k1 + 4], make_tw(t8[k1 >> 3]), mc);
+                bfly2<false, false, true>(x[k0], x[k0 + 4], make_tw(t8[k0 >> 3]), x[k1], x[k1 + 4], make_tw(t8[k1 >> 3]), mc);
             }
             NTT16_LOAD3H(t10, 3, 4);
             NTT16_FENCE();
