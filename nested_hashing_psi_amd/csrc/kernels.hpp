@@ -30,7 +30,7 @@ struct NttPlan {
     const u64 *twc;       // pass-C twiddles in kernel order: per modulus [fwd][inv], see build_twc_table
     const u64 *twc_fold;  // the same for the folded configuration (two half-size slices per limb), or null
     const u64 *twk16 = nullptr;       // ntt16_kernel.h: kernel-ordered pairs of passes 3, 4, one 2^13 slice per limb (ring 2^13), or null
-    const u64 *twk16_fold = nullptr;  // ... two folded 2^13 slices per limb (ring 2^14), or null
+    const u64 *twk16_fold = nullptr;  // ... two folded slices per limb: of 2^13 (ring 2^14) or 2^14 coefficients (ring 2^15), or null
     const DevConsts *dc;  // device pointer
     u32 N, logN;
     u32 num_cus;
@@ -54,10 +54,10 @@ struct NttExtra {
     bool lazy_out = false;  // forward, lane order: leave the residues in [0, 8q) (the consumer reduces anyway)
     bool folded = false;    // set by launch_ntt(.., folded): inverse transforms then hand over unnormalised [0, 4q) residues
 };
-// The 16-coefficients-per-thread kernel (ntt16_kernel.h, kernels_ntt16.hip) for 2^13-coefficient slices: every transform whose
+// The 16-coefficients-per-thread kernel (ntt16_kernel.h, kernels_ntt16.hip) for slices of 2^13 and 2^14 coefficients: every transform whose
 // EVALUATION side is in lane order, and every inverse transform.  Its lane order differs from the 32-coefficient kernel's:
 // a context uses one of the two for all lane-ordered arrays (ntt16_applies).  Returns false when it does not apply.
-void build_twk16_table(const u64 *nat_pairs, u32 s0, std::vector<u64> &out);
+void build_twk16_table(const u64 *nat_pairs, u32 s0, u32 slice_log, std::vector<u64> &out);  // slices of 2^13 or 2^14
 void ntt16_sigma_inverse_map(u32 logN, u32 s0, std::vector<u32> &map);
 // dg (forward, lane order, mod_base 0, mod_count L): the BV key-switch digits of nb polynomials join the launch -- limb (bin, i, j)
 // of dig[nb][L][L][N] = transform of the centred lift into q_j of residue limb i of the COEFFICIENT polynomial d2 + bin * stride2
@@ -72,7 +72,7 @@ bool launch_ntt16(const NttPlan &pl, bool folded, u64 *data, u32 nlimbs, u32 mod
                   hipStream_t st, const NttExtra *ex, const Ntt16Digits *dg = nullptr);
 inline bool ntt16_applies(const NttPlan &pl, bool folded)
 {
-    return !pl.force_generic && pl.twp && (folded ? (pl.twk16_fold && pl.logN == 14) : (pl.twk16 && pl.logN == 13));
+    return !pl.force_generic && pl.twp && (folded ? (pl.twk16_fold && (pl.logN == 14 || pl.logN == 15)) : (pl.twk16 && pl.logN == 13));
 }
 bool launch_ntt_fast(const u64 *twp, const u64 *twc, const DevConsts *dc, u32 N, u32 logN, u32 s0, u64 *data, u32 nlimbs, u32 mod_base,
                      u32 mod_count, bool inverse, bool sigma, u32 num_cus, hipStream_t st, const u64 *lift_src = nullptr,

@@ -6,13 +6,44 @@
 
 namespace piehip {
 
-void build_twk16_table(const u64 *nat_pairs, u32 s0, std::vector<u64> &out) { ntt16::build_twk_table(nat_pairs, s0, out); }
+void build_twk16_table(const u64 *nat_pairs, u32 s0, u32 slice_log, std::vector<u64> &out)
+{
+    if (slice_log == 14)
+        ntt16::build_twk_table_t<14>(nat_pairs, s0, out);
+    else
+        ntt16::build_twk_table_t<13>(nat_pairs, s0, out);
+}
 
 void ntt16_sigma_inverse_map(u32 logN, u32 s0, std::vector<u32> &map)
 {
     const u32 N = 1u << logN, n = N >> s0;
     map.resize(N);
-    for (u32 p = 0; p < N; p++) map[p] = (p / n) * n + ntt16::lane_to_std(p % n);
+    for (u32 p = 0; p < N; p++) map[p] = (p / n) * n + ntt16::lane_to_std_t(p % n, n / 16);
+}
+
+template <u32 LOGNS>
+static void launch_ntt16_t(const ntt16::Args &a, bool inverse, bool lift, u32 num_cus, hipStream_t st)
+{
+    typedef ntt16::Geo<LOGNS> G;
+    constexpr size_t lds = (size_t)G::LDS_WORDS * sizeof(u64);
+    static PerDeviceOnce attr[3];
+    if (attr[inverse ? 1 : (lift ? 2 : 0)].first_on_current_device()) {
+        if (inverse)
+            (void)hipFuncSetAttribute((const void *)ntt16::ntt16_kernel_t<LOGNS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else if (lift)
+            (void)hipFuncSetAttribute((const void *)ntt16::ntt16_kernel_t<LOGNS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else
+            (void)hipFuncSetAttribute((const void *)ntt16::ntt16_kernel_t<LOGNS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    // resident workgroups per CU: two of 512 threads (68 KiB of LDS, 128 VGPRs each) or one of 1024 (136 KiB); persistent beyond
+    const u32 slots = (LOGNS == 13 ? 2u : 1u) * num_cus;
+    const u32 grid = a.nitems < slots ? a.nitems : slots;
+    if (inverse)
+        hipLaunchKernelGGL((ntt16::ntt16_kernel_t<LOGNS, true>), dim3(grid), dim3(G::T), lds, st, a);
+    else if (lift)
+        hipLaunchKernelGGL((ntt16::ntt16_kernel_t<LOGNS, false, true>), dim3(grid), dim3(G::T), lds, st, a);
+    else
+        hipLaunchKernelGGL((ntt16::ntt16_kernel_t<LOGNS, false>), dim3(grid), dim3(G::T), lds, st, a);
 }
 
 bool launch_ntt16(const NttPlan &pl, bool folded, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inverse, bool sigma,
@@ -20,7 +51,8 @@ bool launch_ntt16(const NttPlan &pl, bool folded, u64 *data, u32 nlimbs, u32 mod
 {
     const u64 *twk = folded ? pl.twk16_fold : pl.twk16;
     const u32 s0 = folded ? 1u : 0u;
-    if (pl.force_generic || !twk || !pl.twp || pl.logN - s0 != ntt16::LOGN) return false;
+    const u32 slice_log = pl.logN - s0;
+    if (pl.force_generic || !twk || !pl.twp || (slice_log != 13 && slice_log != 14)) return false;
     if (!inverse && !sigma) return false;  // standard-order output is the 32-coefficient kernel's
     ntt16::Args a;
     a.data = data;
@@ -55,26 +87,11 @@ bool launch_ntt16(const NttPlan &pl, bool folded, u64 *data, u32 nlimbs, u32 mod
         a.lift_stride = dg->stride2;
         a.lift_L = dg->L;
     }
-    constexpr size_t lds = (size_t)ntt16::LDS_WORDS * sizeof(u64);
     const bool lift = a.lift_first != ~0u;
-    static PerDeviceOnce attr[3];
-    if (attr[inverse ? 1 : (lift ? 2 : 0)].first_on_current_device()) {
-        if (inverse)
-            (void)hipFuncSetAttribute((const void *)ntt16::ntt16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else if (lift)
-            (void)hipFuncSetAttribute((const void *)ntt16::ntt16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else
-            (void)hipFuncSetAttribute((const void *)ntt16::ntt16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
-    // two resident workgroups per CU (68 KiB of LDS, 128 VGPRs each); persistent beyond that
-    const u32 slots = 2 * pl.num_cus;
-    const u32 grid = a.nitems < slots ? a.nitems : slots;
-    if (inverse)
-        hipLaunchKernelGGL(ntt16::ntt16_kernel<true>, dim3(grid), dim3(ntt16::T), lds, st, a);
-    else if (lift)
-        hipLaunchKernelGGL((ntt16::ntt16_kernel<false, true>), dim3(grid), dim3(ntt16::T), lds, st, a);
+    if (slice_log == 14)
+        launch_ntt16_t<14>(a, inverse, lift, pl.num_cus, st);
     else
-        hipLaunchKernelGGL(ntt16::ntt16_kernel<false>, dim3(grid), dim3(ntt16::T), lds, st, a);
+        launch_ntt16_t<13>(a, inverse, lift, pl.num_cus, st);
     return true;
 }
 

@@ -33,11 +33,24 @@ namespace ntt16 {
 
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
-static constexpr u32 LOGN = 13;
-static constexpr u32 NS = 1u << LOGN;   // coefficients per slice
-static constexpr u32 T = NS / 16;       // threads per slice
-static constexpr u32 LDS_WORDS = NS + NS / 16;
-static constexpr u32 TWK_PER_SLICE = 8 * 15 * 16 + 8 * 12 * 64;  // kernel-ordered twiddle pairs of passes 3 and 4
+// Slices of 2^13 (512 threads, two workgroups per CU) or 2^14 coefficients (1024 threads, one workgroup per CU: rings of
+// 2^15 as two folded slices per limb).  The wave-local passes 2-4 are the same; pass 1 covers the stages above a wave's 1024
+// elements: 3 stages on 8 rows x 2 columns per thread (16-byte lanes), or 4 stages on 16 rows x 1 column (8-byte lanes).
+template <u32 LOGNS>
+struct Geo {
+    static constexpr u32 LOGN = LOGNS;
+    static constexpr u32 NS = 1u << LOGNS;     // coefficients per slice
+    static constexpr u32 T = NS / 16;          // threads per slice
+    static constexpr u32 W = T / 64;           // waves per slice = 1024-element blocks
+    static constexpr u32 R = NS / 1024;        // rows of pass 1 (stride 1024)
+    static constexpr u32 LOGR = LOGNS - 10;    // stages of pass 1
+    static constexpr u32 CPT = 16 / R;         // columns per thread in pass 1
+    static constexpr u32 LDS_WORDS = NS + NS / 16;
+    static constexpr u32 TWK_PER_SLICE = W * 15 * 16 + W * 12 * 64;  // kernel-ordered twiddle pairs of passes 3 and 4
+};
+// (the 2^13 geometry under its old names: tools/ntt_lab.hip)
+static constexpr u32 LOGN = Geo<13>::LOGN, NS = Geo<13>::NS, T = Geo<13>::T, LDS_WORDS = Geo<13>::LDS_WORDS,
+                     TWK_PER_SLICE = Geo<13>::TWK_PER_SLICE;
 
 __device__ __forceinline__ u32 phi(u32 e) { return e + 2 * (e >> 5); }
 
@@ -143,6 +156,29 @@ __device__ __forceinline__ u64 csub_neg(u64 x, u64 negm)
     return ((u64)hi << 32) | lo;
 }
 
+// the CPT coefficients a thread holds of row r (pass 1): x[CPT r .. CPT r + CPT)
+template <u32 CPT>
+__device__ __forceinline__ void row_get(u64 *x, int r, const u64 *p)
+{
+    if (CPT == 2) {
+        const u64x2 v = *reinterpret_cast<const u64x2 *>(p);
+        x[2 * r] = v.x, x[2 * r + 1] = v.y;
+    } else {
+        x[r] = *p;
+    }
+}
+template <u32 CPT>
+__device__ __forceinline__ void row_put(const u64 *x, int r, u64 *p)
+{
+    if (CPT == 2) {
+        u64x2 v;
+        v.x = x[2 * r], v.y = x[2 * r + 1];
+        *reinterpret_cast<u64x2 *>(p) = v;
+    } else {
+        *p = x[r];
+    }
+}
+
 // DS operations of one wave execute in issue order: a hand-off inside the wave only needs the compiler kept from
 // moving the reads above the writes
 __device__ __forceinline__ void wave_sync()
@@ -183,37 +219,42 @@ enum : u32 {
 
 // Host side: the twiddle pairs of passes 3 and 4 of one (modulus, direction) in kernel order, for every slice of a limb.
 // nat: the N natural-order pairs {w, w_shoup63} (index = 2^stage + group).  out: [1 << s0][TWK_PER_SLICE] pairs.
-inline void build_twk_table(const u64 *nat, u32 s0, std::vector<u64> &out)
+template <u32 LOGNS>
+inline void build_twk_table_t(const u64 *nat, u32 s0, std::vector<u64> &out)
 {
-    out.assign((size_t)(1u << s0) * TWK_PER_SLICE * 2, 0);
+    typedef Geo<LOGNS> G;
+    out.assign((size_t)(1u << s0) * G::TWK_PER_SLICE * 2, 0);
     for (u32 blk = 0; blk < (1u << s0); blk++) {
-        u64 *o = &out[(size_t)blk * TWK_PER_SLICE * 2];
+        u64 *o = &out[(size_t)blk * G::TWK_PER_SLICE * 2];
         auto put = [&](size_t dst, size_t src) {
             o[2 * dst] = nat[2 * src];
             o[2 * dst + 1] = nat[2 * src + 1];
         };
-        for (u32 w = 0; w < 8; w++) {
-            for (u32 sc = 0; sc < 4; sc++)  // pass 3: stages 7 + sc, 128 << sc local groups
+        for (u32 w = 0; w < G::W; w++) {
+            for (u32 sc = 0; sc < 4; sc++)  // pass 3: the four stages below pass 2, 16 W << sc local groups
                 for (u32 jj = 0; jj < (1u << sc); jj++)
                     for (u32 la = 0; la < 16; la++) {
-                        const u32 ml = 128u << sc;
+                        const u32 ml = (16 * G::W) << sc;
                         put(((size_t)w * 15 + ((1u << sc) - 1 + jj)) * 16 + la, ((size_t)ml << s0) + (size_t)blk * ml + (((16 * w + la) << sc) + jj));
                     }
-            for (u32 l = 0; l < 64; l++) {  // pass 4: stages 11 (slots 0..3) and 12 (slots 4..11)
+            for (u32 l = 0; l < 64; l++) {  // pass 4: the last two stages (slots 0..3 and 4..11)
+                const u32 m11 = 256 * G::W, m12 = 512 * G::W;
                 for (u32 jj = 0; jj < 4; jj++)
-                    put(8 * 15 * 16 + ((size_t)w * 12 + jj) * 64 + l, ((size_t)2048 << s0) + (size_t)blk * 2048 + 256 * w + 4 * l + jj);
+                    put(G::W * 15 * 16 + ((size_t)w * 12 + jj) * 64 + l, ((size_t)m11 << s0) + (size_t)blk * m11 + 256 * w + 4 * l + jj);
                 for (u32 jj = 0; jj < 8; jj++)
-                    put(8 * 15 * 16 + ((size_t)w * 12 + 4 + jj) * 64 + l, ((size_t)4096 << s0) + (size_t)blk * 4096 + 512 * w + 8 * l + jj);
+                    put(G::W * 15 * 16 + ((size_t)w * 12 + 4 + jj) * 64 + l, ((size_t)m12 << s0) + (size_t)blk * m12 + 512 * w + 8 * l + jj);
             }
         }
     }
 }
-// lane-order position p of a slice -> standard (bit-reversed) position
-inline u32 lane_to_std(u32 p)
+inline void build_twk_table(const u64 *nat, u32 s0, std::vector<u64> &out) { build_twk_table_t<13>(nat, s0, out); }
+// lane-order position p of a slice of T * 16 coefficients -> standard (bit-reversed) position
+inline u32 lane_to_std_t(u32 p, u32 threads)
 {
-    const u32 tau = (p >> 1) % T, j = (p >> 1) / T;
+    const u32 tau = (p >> 1) % threads, j = (p >> 1) / threads;
     return 16 * tau + 2 * j + (p & 1);
 }
+inline u32 lane_to_std(u32 p) { return lane_to_std_t(p, T); }
 
 // in-kernel cycle stamps are a tooling build (tools/ntt_lab.hip defines NTT16_STAMP before including this file)
 #ifndef NTT16_STAMP
@@ -234,9 +275,11 @@ inline u32 lane_to_std(u32 p)
 
 // LIFT (forward only): the launch may carry key-switch digit items (Args::lift_first); a separate instantiation, so that the
 // plain forward transform does not pay for the lift's registers
-template <bool INV, bool LIFT = false>
-__global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
+template <u32 LOGNS, bool INV, bool LIFT = false>
+__global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
 {
+    typedef Geo<LOGNS> G;
+    constexpr u32 NS = G::NS, T = G::T, R = G::R, LOGR = G::LOGR, CPT = G::CPT, TWK_PER_SLICE = G::TWK_PER_SLICE;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const u32 tau = threadIdx.x;
     const u32 w = __builtin_amdgcn_readfirstlane(tau >> 6), l = tau & 63;
@@ -246,11 +289,12 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
     //   pass 2: e = 1024 w + 64 k + l       -> p2 + 68 k              p2 = phi(1024 w + l)
     //   pass 3: e = 1024 w + 64 a + 4 k + c -> p3 + 4 k + 2 (k >> 3)  p3 = 1088 w + 68 a + c
     //   pass 4: e = 1024 w + 16 l + k       -> p4 + k                 p4 = phi(1024 w + 16 l)
-    u64 *const p1 = lds + phi(2 * tau);
+    u64 *const p1 = lds + phi(CPT * tau);
     u64 *const p2 = lds + phi(1024 * w + l);
     u64 *const p3 = lds + 1088 * w + 68 * la + lc;
     u64 *const p4 = lds + phi(1024 * w + 16 * l);
-    const u32 voff = 2 * tau;  // lane offset (in words) of both global access patterns: rows 1024 r + 2 tau, pairs 2 (512 j + tau)
+    const u32 voff = 2 * tau;    // lane offset (in words) of the lane-ordered pairs 2 (T j + tau)
+    const u32 coff = CPT * tau;  // ... and of the row accesses 1024 r + CPT tau (pass 1)
     u64 x[16];
     // item -> (limb, slice of the limb); forward launches may enumerate [nb][4][skip_M] without the Q limbs of slots 0, 1
     auto limb_of = [&](u32 it) -> u32 {
@@ -277,7 +321,7 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
         const TwS tw = (TwS)uniform_addr(a.twp + ((size_t)mod * 2 + (INV ? 1 : 0)) * a.N);
         const u64x2 *__restrict__ twk = a.twk + (((size_t)mod * 2 + (INV ? 1 : 0)) << a.s0) * TWK_PER_SLICE + (size_t)blk * TWK_PER_SLICE;
         const u64x2 *__restrict__ tw3 = twk + (size_t)w * 15 * 16;                 // [slot 0..14][16 a]
-        const u64x2 *__restrict__ tw4 = twk + 8 * 15 * 16 + (size_t)w * 12 * 64;   // [slot 0..11][64 l]
+        const u64x2 *__restrict__ tw4 = twk + G::W * 15 * 16 + (size_t)w * 12 * 64;   // [slot 0..11][64 l]
         // per-lane twiddles of passes 3 and 4, loaded one stage ahead of their use (named by stage: 7, 8, 9, 10, 11, 12)
         u64x2 t7[1], t8[2], t9[4], t10[8], t11[4], t12[8];
 #define NTT16_LOAD3(dst, sc)                                                       \
@@ -314,51 +358,44 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
                     fw.x = dcs->fold_w[lj];
                     fw.y = dcs->fold_w_sh[lj] >> 1;
                     const Tw t = make_tw(fw);
+                    u64 y[16];  // the other half of the limb
 #pragma unroll
-                    for (int r = 0; r < 8; r++) {
-                        const u64x2 u = *reinterpret_cast<const u64x2 *>(src + 1024 * r + voff);
-                        const u64x2 v = *reinterpret_cast<const u64x2 *>(src + NS + 1024 * r + voff);
-                        u64 u0 = lift1(u.x), u1 = lift1(u.y), v0 = lift1(v.x), v1 = lift1(v.y);
-                        bfly2<false, true>(u0, v0, t, u1, v1, t, mc);
-                        x[2 * r] = blk ? v0 : u0;
-                        x[2 * r + 1] = blk ? v1 : u1;
+                    for (int r = 0; r < (int)R; r++) {
+                        row_get<CPT>(x, r, src + 1024 * r + coff);
+                        row_get<CPT>(y, r, src + NS + 1024 * r + coff);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        u64 u0 = lift1(x[k]), v0 = lift1(y[k]);
+                        bfly<false, true>(u0, v0, t, mc);
+                        x[k] = blk ? v0 : u0;
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 8; r++) {
-                        const u64x2 u = *reinterpret_cast<const u64x2 *>(src + 1024 * r + voff);
-                        x[2 * r] = lift1(u.x);
-                        x[2 * r + 1] = lift1(u.y);
-                    }
+                    for (int r = 0; r < (int)R; r++) row_get<CPT>(x, r, src + 1024 * r + coff);
+#pragma unroll
+                    for (int k = 0; k < 16; k++) x[k] = lift1(x[k]);
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const u64x2 v = *reinterpret_cast<const u64x2 *>(g + 1024 * r + voff);
-                    x[2 * r] = v.x;
-                    x[2 * r + 1] = v.y;
-                }
+                for (int r = 0; r < (int)R; r++) row_get<CPT>(x, r, g + 1024 * r + coff);
             }
 #pragma unroll
-            for (int s = 0; s < 3; s++) {
-                const int d = 4 >> s;
+            for (int s = 0; s < (int)LOGR; s++) {
+                const int d = (int)(R >> 1) >> s;
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
+                for (int r = 0; r < (int)R; r++) {
                     if (r & d) continue;
-                    const Tw t = make_tw(NTT16_TWL(1u << s, (u32)r >> (3 - s)));
-                    bfly2<false, true>(x[2 * r], x[2 * (r + d)], t, x[2 * r + 1], x[2 * (r + d) + 1], t, mc);
+                    const Tw t = make_tw(NTT16_TWL(1u << s, (u32)r >> (LOGR - s)));
+#pragma unroll
+                    for (int c = 0; c < (int)CPT; c++) bfly<false, true>(x[CPT * r + c], x[CPT * (r + d) + c], t, mc);
                 }
             }
             NTT16_STAMP(1);
             __syncthreads();  // every wave has finished the previous slice's LDS reads
             NTT16_STAMP(2);
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                u64x2 v;
-                v.x = x[2 * r];
-                v.y = x[2 * r + 1];
-                *reinterpret_cast<u64x2 *>(p1 + 1088 * r) = v;
-            }
+            for (int r = 0; r < (int)R; r++) row_put<CPT>(x, r, p1 + 1088 * r);
             NTT16_STAMP(3);
             __syncthreads();
             NTT16_STAMP(4);
@@ -372,8 +409,8 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
 #pragma unroll
                 for (int mm = 0; mm < 8; mm += 2) {
                     const int k0 = bfly_lo(mm, d), k1 = bfly_lo(mm + 1, d);
-                    const Tw t0 = make_tw(NTT16_TWL(8u << sb, (w << sb) + ((u32)k0 >> (4 - sb))));
-                    const Tw t1 = make_tw(NTT16_TWL(8u << sb, (w << sb) + ((u32)k1 >> (4 - sb))));
+                    const Tw t0 = make_tw(NTT16_TWL(G::W << sb, (w << sb) + ((u32)k0 >> (4 - sb))));
+                    const Tw t1 = make_tw(NTT16_TWL(G::W << sb, (w << sb) + ((u32)k1 >> (4 - sb))));
                     bfly2<false, true>(x[k0], x[k0 + d], t0, x[k1], x[k1 + d], t1, mc);
                 }
             }
@@ -465,12 +502,12 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
             NTT16_LOAD4(t12, 4, 8);
             if (a.flags & F_STD_IN) {
                 // standard order: coalesced rows through LDS
-                u64x2 yv[8];
+                u64 yv[16];
 #pragma unroll
-                for (int r = 0; r < 8; r++) yv[r] = *reinterpret_cast<const u64x2 *>(g + 1024 * r + voff);
+                for (int r = 0; r < (int)R; r++) row_get<CPT>(yv, r, g + 1024 * r + coff);
                 __syncthreads();  // previous slice's readers of the image are done
 #pragma unroll
-                for (int r = 0; r < 8; r++) *reinterpret_cast<u64x2 *>(p1 + 1088 * r) = yv[r];
+                for (int r = 0; r < (int)R; r++) row_put<CPT>(yv, r, p1 + 1088 * r);
                 __syncthreads();
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -564,48 +601,41 @@ __global__ void __launch_bounds__(T, 4) ntt16_kernel(Args a)
 #pragma unroll
                 for (int mm = 0; mm < 8; mm += 2) {
                     const int k0 = bfly_lo(mm, d), k1 = bfly_lo(mm + 1, d);
-                    const Tw t0 = make_tw(NTT16_TWL(8u << sb, (w << sb) + ((u32)k0 >> (4 - sb))));
-                    const Tw t1 = make_tw(NTT16_TWL(8u << sb, (w << sb) + ((u32)k1 >> (4 - sb))));
+                    const Tw t0 = make_tw(NTT16_TWL(G::W << sb, (w << sb) + ((u32)k0 >> (4 - sb))));
+                    const Tw t1 = make_tw(NTT16_TWL(G::W << sb, (w << sb) + ((u32)k1 >> (4 - sb))));
                     bfly2<true, true>(x[k0], x[k0 + d], t0, x[k1], x[k1 + d], t1, mc);
                 }
             }
 #pragma unroll
             for (int k = 0; k < 16; k++) p2[68 * k] = x[k];
             __syncthreads();
-            // ---- pass 1': stages 2..0, stored straight to HBM ------------------------------------------------------------------
+            // ---- pass 1': the top LOGR stages, stored straight to HBM ------------------------------------------------------------------
             NTT16_PASS_PRIO(0);
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const u64x2 v = *reinterpret_cast<const u64x2 *>(p1 + 1088 * r);
-                x[2 * r] = v.x;
-                x[2 * r + 1] = v.y;
-            }
+            for (int r = 0; r < (int)R; r++) row_get<CPT>(x, r, p1 + 1088 * r);
 #pragma unroll
-            for (int s = 2; s >= 0; s--) {
-                const int d = 4 >> s;
+            for (int s = (int)LOGR - 1; s >= 0; s--) {
+                const int d = (int)(R >> 1) >> s;
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
+                for (int r = 0; r < (int)R; r++) {
                     if (r & d) continue;
-                    const Tw t = make_tw(NTT16_TWL(1u << s, (u32)r >> (3 - s)));
-                    bfly2<true, true>(x[2 * r], x[2 * (r + d)], t, x[2 * r + 1], x[2 * (r + d) + 1], t, mc);
+                    const Tw t = make_tw(NTT16_TWL(1u << s, (u32)r >> (LOGR - s)));
+#pragma unroll
+                    for (int c = 0; c < (int)CPT; c++) bfly<true, true>(x[CPT * r + c], x[CPT * (r + d) + c], t, mc);
                 }
             }
             const u64 n_inv = dcs->mod[mod].n_inv, n_inv_sh = dcs->mod[mod].n_inv_sh;
+            if (!(a.flags & F_FOLDED)) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                u64x2 v;
-                if (a.flags & F_FOLDED) {
-                    v.x = x[2 * r];
-                    v.y = x[2 * r + 1];
-                } else if (a.s0 == 0) {
-                    v.x = csub_neg(mul_shoup_lazy(x[2 * r], n_inv, n_inv_sh, q), 0 - q);
-                    v.y = csub_neg(mul_shoup_lazy(x[2 * r + 1], n_inv, n_inv_sh, q), 0 - q);
-                } else {  // split transform: the global-memory stages expect canonical residues
-                    v.x = csub_neg(csub_neg(x[2 * r], 0 - q2), 0 - q);
-                    v.y = csub_neg(csub_neg(x[2 * r + 1], 0 - q2), 0 - q);
+                for (int k = 0; k < 16; k++) {
+                    if (a.s0 == 0)
+                        x[k] = csub_neg(mul_shoup_lazy(x[k], n_inv, n_inv_sh, q), 0 - q);
+                    else  // split transform: the global-memory stages expect canonical residues
+                        x[k] = csub_neg(csub_neg(x[k], 0 - q2), 0 - q);
                 }
-                *reinterpret_cast<u64x2 *>(g + 1024 * r + voff) = v;
             }
+#pragma unroll
+            for (int r = 0; r < (int)R; r++) row_put<CPT>(x, r, g + 1024 * r + coff);
         }
     }
 }

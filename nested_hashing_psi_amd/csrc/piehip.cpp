@@ -105,7 +105,7 @@ struct piehip_ctx {
     u32 *d_sigma_inv = nullptr;  // lane-order position -> standard position (identity for small rings)
     u32 sigma_T = 0;             // threads per slice of the transform that defines the lane order
     u32 sigma_kp = 16;           // ... and coefficient pairs per thread (16: kernels_ntt_fast.hip, 8: ntt16_kernel.h)
-    u64 *d_twk16 = nullptr;      // ntt16_kernel.h tables (2^13-coefficient slices: ring 2^13, or ring 2^14 folded)
+    u64 *d_twk16 = nullptr;      // ntt16_kernel.h tables (ring 2^13 as one slice per limb; rings 2^14, 2^15 as two folded slices)
     bool small_moduli = false;   // all Q and P moduli in (2^59, 2^60): v_mad_u64_u32 column accumulators, one-word Barrett
     bool sigma_on = false;       // the register-blocked NTT (and hence the lane order) applies to this context
     u64 *d_evk_sigma = nullptr, *d_masks_sigma = nullptr;  // lane-ordered copies of key and masks
@@ -481,12 +481,12 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
                 CHK_(hipMemcpy(h->d_twc_fold, all.data(), all.size() * sizeof(u64), hipMemcpyHostToDevice));
                 h->fold_on = true;
             }
-            if (h->hp.logN == 13 || h->hp.logN == 14) {  // 2^13-coefficient slices: the 16-coefficients-per-thread kernel
-                const u32 s16 = h->hp.logN - 13;
+            if (h->hp.logN >= 13 && h->hp.logN <= 15) {  // the 16-coefficients-per-thread kernel: slices of 2^13 (rings 2^13, 2^14) or 2^14 (ring 2^15)
+                const u32 s16 = h->hp.logN == 13 ? 0u : 1u;
                 all.clear();
                 for (u32 a = 0; a <= M; a++)
                     for (u32 dir = 0; dir < 2; dir++) {
-                        build_twk16_table(&pairs[((size_t)a * 2 + dir) * 2 * N], s16, one);
+                        build_twk16_table(&pairs[((size_t)a * 2 + dir) * 2 * N], s16, h->hp.logN - s16, one);
                         all.insert(all.end(), one.begin(), one.end());
                     }
                 CHK_(hipMalloc((void **)&h->d_twk16, all.size() * sizeof(u64)));
@@ -506,7 +506,7 @@ int piehip_create(piehip_handle *out, uint32_t N, uint32_t L, uint64_t t, const 
     h->plan.logN = h->hp.logN;
     h->plan.force_generic = false;
     if (h->hp.logN == 13) h->plan.twk16 = h->d_twk16;
-    if (h->hp.logN == 14) h->plan.twk16_fold = h->d_twk16;
+    if (h->hp.logN == 14 || h->hp.logN == 15) h->plan.twk16_fold = h->d_twk16;
     const bool use16 = ntt16_applies(h->plan, h->fold_on);  // which kernel defines this context's lane order
     {
         std::vector<u32> smap;

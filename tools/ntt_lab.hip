@@ -33,6 +33,17 @@ __device__ unsigned long long g_stamps[8 * 16];
 
 using namespace piehip;
 using namespace piehip::ntt16;
+// slice geometry under test: -DLAB_LOGNS=14 for the 2^14-coefficient slices (1024 threads, one workgroup per CU)
+#ifndef LAB_LOGNS
+#define LAB_LOGNS 13
+#endif
+typedef Geo<LAB_LOGNS> LG;
+#define LOGN LG::LOGN
+#define NS LG::NS
+#define T LG::T
+#define LDS_WORDS LG::LDS_WORDS
+#define lane_to_std(p) lane_to_std_t((p), (1u << LAB_LOGNS) / 16)
+static const unsigned LAB_SLOTS = (LAB_LOGNS == 13 ? 2u : 1u) * 256u;   // resident workgroups on 256 CUs
 
 #define CK(x)                                                                     \
     do {                                                                          \
@@ -73,7 +84,7 @@ int main(int argc, char **argv)
         std::vector<u64> one;
         for (u32 m = 0; m < nmod; m++)
             for (u32 d = 0; d < 2; d++) {
-                build_twk_table(&twp[((size_t)m * 2 + d) * N * 2], s0, one);
+                build_twk_table_t<LAB_LOGNS>(&twp[((size_t)m * 2 + d) * N * 2], s0, one);
                 twk.insert(twk.end(), one.begin(), one.end());
             }
     }
@@ -86,12 +97,12 @@ int main(int argc, char **argv)
     CK(hipMemcpy(d_twk, twk.data(), twk.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_dc, &dc, sizeof(dc), hipMemcpyHostToDevice));
     const size_t lds = LDS_WORDS * 8;
-    CK(hipFuncSetAttribute((const void *)ntt16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CK(hipFuncSetAttribute((const void *)ntt16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void *)ntt16_kernel_t<LAB_LOGNS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void *)ntt16_kernel_t<LAB_LOGNS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int occ = 0;
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt16_kernel<false>, T, lds));
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (ntt16_kernel_t<LAB_LOGNS, false>), T, lds));
     printf("occupancy: %d blocks/CU forward", occ);
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ntt16_kernel<true>, T, lds));
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (ntt16_kernel_t<LAB_LOGNS, true>), T, lds));
     printf(", %d inverse\n", occ);
 
     // ---- correctness on a small batch ------------------------------------------------------------------------------------
@@ -112,9 +123,9 @@ int main(int argc, char **argv)
             a.flags = inv ? (F_FOLDED | (std_in ? F_STD_IN : 0)) : 0;
             a.lift_first = ~0u;
             if (inv)
-                hipLaunchKernelGGL(ntt16_kernel<true>, dim3(5), dim3(T), lds, 0, a);   // 5 blocks: every block loops
+                hipLaunchKernelGGL((ntt16_kernel_t<LAB_LOGNS, true>), dim3(5), dim3(T), lds, 0, a);   // 5 blocks: every block loops
             else
-                hipLaunchKernelGGL(ntt16_kernel<false>, dim3(5), dim3(T), lds, 0, a);
+                hipLaunchKernelGGL((ntt16_kernel_t<LAB_LOGNS, false>), dim3(5), dim3(T), lds, 0, a);
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
             CK(hipFree(d));
@@ -173,7 +184,7 @@ int main(int argc, char **argv)
 #endif
 
 #ifdef LAB_STAMPS
-    for (u32 grid : {256u, 512u}) {
+    for (u32 grid : {LAB_SLOTS / 2, LAB_SLOTS}) {
         const u32 nitems = 3 * grid;
         u64 *d;
         CK(hipMalloc((void **)&d, (size_t)nitems * NS * 8));
@@ -184,12 +195,12 @@ int main(int argc, char **argv)
         a.mod_base = 0, a.mod_count = nmod;
         a.flags = F_LAZY_OUT;
         a.lift_first = ~0u;
-        for (int rep = 0; rep < 400; rep++) hipLaunchKernelGGL(ntt16_kernel<false>, dim3(grid), dim3(T), lds, 0, a);
+        for (int rep = 0; rep < 400; rep++) hipLaunchKernelGGL((ntt16_kernel_t<LAB_LOGNS, false>), dim3(grid), dim3(T), lds, 0, a);
         CK(hipDeviceSynchronize());
         unsigned long long st[8 * 16];
         CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st)));
         static const char *names[9] = {"load", "pass1", "barA", "ldsW", "barB", "rd+pass2", "pass3", "pass4", "store"};
-        printf("forward, %u blocks (%u per CU): cycles per phase of the second slice (s_memtime ticks)\n", grid, grid / 256);
+        printf("forward, %u blocks (%u/2 per CU): cycles per phase of the second slice (s_memtime ticks)\n", grid, grid / 128);
         for (int w = 0; w < 8; w++) {
             printf("  wave %d:", w);
             for (int i = 1; i <= 8; i++) printf(" %s %llu", names[i], st[w * 16 + i] - st[w * 16 + i - 1]);
@@ -214,7 +225,7 @@ int main(int argc, char **argv)
             a.data = d, a.twp = (const u64x2 *)d_twp, a.twk = (const u64x2 *)d_twk, a.dc = d_dc, a.N = N, a.s0 = s0, a.nitems = nitems;
             a.mod_base = 0, a.mod_count = nmod;
             a.flags = inv ? F_FOLDED : F_LAZY_OUT;
-            const u32 grid = nitems < 512 ? nitems : 512;
+            const u32 grid = nitems < LAB_SLOTS ? nitems : LAB_SLOTS;
             a.lift_first = ~0u;
             hipEvent_t e0, e1;
             CK(hipEventCreate(&e0));
@@ -223,9 +234,9 @@ int main(int argc, char **argv)
             for (int it = 0; it < iters + 3; it++) {
                 if (it == 3) CK(hipEventRecord(e0, 0));
                 if (inv)
-                    hipLaunchKernelGGL(ntt16_kernel<true>, dim3(grid), dim3(T), lds, 0, a);
+                    hipLaunchKernelGGL((ntt16_kernel_t<LAB_LOGNS, true>), dim3(grid), dim3(T), lds, 0, a);
                 else
-                    hipLaunchKernelGGL(ntt16_kernel<false>, dim3(grid), dim3(T), lds, 0, a);
+                    hipLaunchKernelGGL((ntt16_kernel_t<LAB_LOGNS, false>), dim3(grid), dim3(T), lds, 0, a);
             }
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
