@@ -115,6 +115,10 @@ void launch_expand_q_to_qp(const DevConsts *dc, u32 N, u32 L, const u64 *in, siz
 void launch_scale_pq_expand(const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t in_stride_outer,
                             size_t in_stride_inner, u32 n_outer, u64 *out, u32 out_polys, u32 out_slot, hipStream_t st,
                             bool fold = false);
+// both conversions of a ciphertext multiplication in one launch: X (polynomials at x + o*sx + c*si) centred-lifted into slots 0, 1
+// of out[n_outer][4][M][N], Y (at y + o*sy + c*si) scaled by P/Q into slots 2, 3
+void launch_expand_both(const DevConsts *dc, u32 N, u32 L, const u64 *x, size_t sx, const u64 *y, size_t sy, size_t si, u32 n_outer,
+                        u64 *out, hipStream_t st, bool fold = false, bool skip_q = false);
 // e[nb][4][M][N] (a0 a1 b0 b1, EVALUATION) -> d[nb][3][M][N]
 void launch_tensor(const DevConsts *dc, u32 N, u32 M, const u64 *e, u64 *d, u32 nb, hipStream_t st);
 // d[nb][3][M][N] (COEFFICIENT) -> components 0,1 to out01 + bin*stride01 + c*L*N, component 2 to out2 + bin*stride2

@@ -697,15 +697,15 @@ __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 (&x
 
 // SKIPQ (centred lift only): leave the Q limbs of the output alone, they already hold the operand's EVALUATION form
 template <bool SCALE, bool FOLD, u32 L, bool MAD, bool SKIPQ>
-__global__ void __launch_bounds__(TPB) expand_kernel(const DevConsts *__restrict__ dc, u32 N, const u64 *__restrict__ in,
-                                                     size_t so, size_t si, u64 *__restrict__ out, u32 out_polys, u32 out_slot)
+__device__ __forceinline__ void expand_body(const DevConsts *__restrict__ dc, u32 N, const u64 *__restrict__ in, size_t so, size_t si,
+                                            u64 *__restrict__ out, u32 out_polys, u32 out_slot, u32 by)
 {
     // the residues x_i themselves are not needed: the folded load multiplies by N^-1 (Q/q_i)^-1 in one go
     constexpr bool YIN = FOLD && (SCALE || SKIPQ);
     const u32 n = blockIdx.x * TPB + threadIdx.x;
     const u32 H = N / 2;
     if (n >= (FOLD ? H : N)) return;
-    const u32 o = blockIdx.y >> 1, c = blockIdx.y & 1;
+    const u32 o = by >> 1, c = by & 1;
     constexpr u32 M = 2 * L + 1;
     const u64 *pin = in + (size_t)o * so + (size_t)c * si + n;
     u64 *pout = out + ((size_t)(o * out_polys + out_slot + c) * M) * N + n;
@@ -742,6 +742,43 @@ __global__ void __launch_bounds__(TPB) expand_kernel(const DevConsts *__restrict
             pout[(size_t)a * N] = y[0][a];
         }
     }
+}
+
+template <bool SCALE, bool FOLD, u32 L, bool MAD, bool SKIPQ>
+__global__ void __launch_bounds__(TPB) expand_kernel(const DevConsts *__restrict__ dc, u32 N, const u64 *__restrict__ in,
+                                                     size_t so, size_t si, u64 *__restrict__ out, u32 out_polys, u32 out_slot)
+{
+    expand_body<SCALE, FOLD, L, MAD, SKIPQ>(dc, N, in, so, si, out, out_polys, out_slot, blockIdx.y);
+}
+// Both operands of a ciphertext multiplication in one launch: rows [0, 2 n) of the grid scale operand Y (P/Q scaling, the
+// longer body: first, so that the shorter rows fill in behind it), rows [2 n, 4 n) lift operand X.  As two launches each was
+// a single round of 3.5 / 1.75 waves per SIMD with every wave in the same load - compute - store phase; together the rounds
+// interleave (12.4 + 20.6 us -> one launch).  Writes out[n][4][M][N]: X into slots 0, 1, Y into slots 2, 3.
+template <bool FOLD, u32 L, bool MAD, bool SKIPQ>
+__global__ void __launch_bounds__(TPB) expand_both_kernel(const DevConsts *__restrict__ dc, u32 N, const u64 *__restrict__ x, size_t sx,
+                                                          const u64 *__restrict__ y, size_t sy, size_t si, u64 *__restrict__ out,
+                                                          u32 n_outer)
+{
+    if (blockIdx.y < 2 * n_outer)
+        expand_body<true, FOLD, L, MAD, false>(dc, N, y, sy, si, out, 4, 2, blockIdx.y);
+    else
+        expand_body<false, FOLD, L, MAD, SKIPQ>(dc, N, x, sx, si, out, 4, 0, blockIdx.y - 2 * n_outer);
+}
+void launch_expand_both(const DevConsts *dc, u32 N, u32 L, const u64 *x, size_t sx, const u64 *y, size_t sy, size_t si, u32 n_outer,
+                        u64 *out, hipStream_t st, bool fold, bool skip_q)
+{
+    dim3 grid(((fold ? N / 2 : N) + TPB - 1) / TPB, n_outer * 4);
+#define EB(F_, L_, M_, Q_) hipLaunchKernelGGL((expand_both_kernel<F_, L_, M_, Q_>), grid, dim3(TPB), 0, st, dc, N, x, sx, y, sy, si, out, n_outer)
+#define EBL(L_)                                                                          \
+    case L_:                                                                             \
+        if (fold && g_small_moduli) { if (skip_q) EB(true, L_, true, true); else EB(true, L_, true, false); }      \
+        else if (fold) { if (skip_q) EB(true, L_, false, true); else EB(true, L_, false, false); }                 \
+        else if (g_small_moduli) { if (skip_q) EB(false, L_, true, true); else EB(false, L_, true, false); }       \
+        else { if (skip_q) EB(false, L_, false, true); else EB(false, L_, false, false); }                         \
+        break;
+    switch (L) { EBL(1) EBL(2) EBL(3) EBL(4) EBL(5) EBL(6) EBL(7) }
+#undef EBL
+#undef EB
 }
 
 static void launch_expand_common(bool scale, bool fold, const DevConsts *dc, u32 N, u32 L, const u64 *in, size_t so, size_t si,

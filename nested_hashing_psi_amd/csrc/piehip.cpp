@@ -334,8 +334,7 @@ static void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const 
     set_small_moduli(h->small_moduli);
     {
         ProfScope ps(h, PIEHIP_K_EXPAND, W * nb * (4.0 * L + 4.0 * M));
-        launch_expand_q_to_qp(h->d_dc, N, L, x, sx, LN, nb, w.eqp, 4, 0, h->stream, h->fold_on, xq_ready);
-        launch_scale_pq_expand(h->d_dc, N, L, y, sy, LN, nb, w.eqp, 4, 2, h->stream, h->fold_on);
+        launch_expand_both(h->d_dc, N, L, x, sx, y, sy, LN, nb, w.eqp, h->stream, h->fold_on, xq_ready);
     }
     // the QP operands and the tensor result never leave the library: lane order, no LDS transposes
     {
