@@ -304,22 +304,23 @@ __device__ __forceinline__ u64 reduce123_u(U128 z, const Mod &m, u64 negq, u64 n
 // moves, three 64-bit low products through v_mul_lo_u32 + v_add3_u32, a subtraction through VCC with its wait state); the NTT
 // butterfly's formulation does it in 12 -- quotient estimate from the 63-bit constant floor(w 2^63 / q) with three multiplier
 // operations (error <= 3), remainder a w + qe (2^64 - q) on two v_mad_u64_u32 chains -- plus two sign-mask subtractions for a
-// canonical result.  Temporaries whose halves are needed live in fixed registers v84-v95 (an asm operand cannot name the
+// canonical result.  Temporaries whose halves are needed live in fixed registers v60-v71 (low enough that scale_round stays at
+// 76 VGPRs = six waves per SIMD: its 5.25 waves per SIMD are then one round; an asm operand cannot name the
 // halves of a 64-bit pair); constants are SGPR operands, one per instruction (constant-bus limit of VOP3 on gfx9).
-#define PIE_ASM_CLOB "vcc", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95"
-// a < 2^63, w < q < 2^60: v[88:89] <- all but the last product of a w mod q + {0..3} q, v[86:87] <- the quotient estimate
+#define PIE_ASM_CLOB "vcc", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71"
+// a < 2^63, w < q < 2^60: v[64:65] <- all but the last product of a w mod q + {0..3} q, v[62:63] <- the quotient estimate
 #define PIE_SHOUP63_HEAD                                        \
-    "v_mad_u64_u32 v[84:85], vcc, %[al], %[sh], 0\n\t"          \
-    "v_mad_u64_u32 v[88:89], vcc, %[al], %[wl], 0\n\t"          \
-    "v_mad_u64_u32 v[84:85], vcc, %[ah], %[sl], v[84:85]\n\t"   \
-    "v_mad_u64_u32 v[90:91], vcc, %[al], %[wh], 0\n\t"          \
-    "v_lshlrev_b32 v94, 1, %[ah]\n\t"                           \
-    "v_mad_u64_u32 v[90:91], vcc, %[ah], %[wl], v[90:91]\n\t"   \
-    "v_lshrrev_b64 v[84:85], 31, v[84:85]\n\t"                  \
-    "v_mad_u64_u32 v[86:87], vcc, v94, %[sh], v[84:85]\n\t"     \
-    "v_mad_u64_u32 v[90:91], vcc, v86, %[nqh], v[90:91]\n\t"    \
-    "v_mad_u64_u32 v[90:91], vcc, v87, %[nql], v[90:91]\n\t"    \
-    "v_add_u32 v89, v89, v90\n\t"
+    "v_mad_u64_u32 v[60:61], vcc, %[al], %[sh], 0\n\t"          \
+    "v_mad_u64_u32 v[64:65], vcc, %[al], %[wl], 0\n\t"          \
+    "v_mad_u64_u32 v[60:61], vcc, %[ah], %[sl], v[60:61]\n\t"   \
+    "v_mad_u64_u32 v[66:67], vcc, %[al], %[wh], 0\n\t"          \
+    "v_lshlrev_b32 v70, 1, %[ah]\n\t"                           \
+    "v_mad_u64_u32 v[66:67], vcc, %[ah], %[wl], v[66:67]\n\t"   \
+    "v_lshrrev_b64 v[60:61], 31, v[60:61]\n\t"                  \
+    "v_mad_u64_u32 v[62:63], vcc, v70, %[sh], v[60:61]\n\t"     \
+    "v_mad_u64_u32 v[66:67], vcc, v62, %[nqh], v[66:67]\n\t"    \
+    "v_mad_u64_u32 v[66:67], vcc, v63, %[nql], v[66:67]\n\t"    \
+    "v_add_u32 v65, v65, v66\n\t"
 #define PIE_SHOUP63_IN(a, w, wsh, nq)                                                                                        \
     [al] "v"((u32)(a)), [ah] "v"((u32)((a) >> 32)), [wl] "s"((u32)(w)), [wh] "s"((u32)((w) >> 32)), [sl] "s"((u32)((wsh) >> 1)), \
         [sh] "s"((u32)((wsh) >> 33)), [nql] "s"((u32)(nq)), [nqh] "s"((u32)((nq) >> 32))
@@ -328,7 +329,7 @@ __device__ __forceinline__ u64 shoup63_lazy(u64 a, u64 w, u64 wsh, u64 nq)
 {
     u64 r;
     asm(PIE_SHOUP63_HEAD
-        "v_mad_u64_u32 %[r], vcc, v86, %[nql], v[88:89]"
+        "v_mad_u64_u32 %[r], vcc, v62, %[nql], v[64:65]"
         : [r] "=v"(r)
         : PIE_SHOUP63_IN(a, w, wsh, nq)
         : PIE_ASM_CLOB);
@@ -340,15 +341,15 @@ __device__ __forceinline__ u64 shoup63(u64 a, u64 w, u64 wsh, u64 nq)
     u32 lo, hi;
     const u64 n2q = 2 * nq;  // 2^64 - 2q
     asm(PIE_SHOUP63_HEAD
-        "v_mad_u64_u32 v[88:89], vcc, v86, %[nql], v[88:89]\n\t"
-        "v_lshl_add_u64 v[92:93], v[88:89], 0, %[n2q]\n\t"
-        "v_ashrrev_i32 v95, 31, v93\n\t"
-        "v_bfi_b32 v88, v95, v88, v92\n\t"
-        "v_bfi_b32 v89, v95, v89, v93\n\t"
-        "v_lshl_add_u64 v[92:93], v[88:89], 0, %[n1q]\n\t"
-        "v_ashrrev_i32 v95, 31, v93\n\t"
-        "v_bfi_b32 %[lo], v95, v88, v92\n\t"
-        "v_bfi_b32 %[hi], v95, v89, v93"
+        "v_mad_u64_u32 v[64:65], vcc, v62, %[nql], v[64:65]\n\t"
+        "v_lshl_add_u64 v[68:69], v[64:65], 0, %[n2q]\n\t"
+        "v_ashrrev_i32 v71, 31, v69\n\t"
+        "v_bfi_b32 v64, v71, v64, v68\n\t"
+        "v_bfi_b32 v65, v71, v65, v69\n\t"
+        "v_lshl_add_u64 v[68:69], v[64:65], 0, %[n1q]\n\t"
+        "v_ashrrev_i32 v71, 31, v69\n\t"
+        "v_bfi_b32 %[lo], v71, v64, v68\n\t"
+        "v_bfi_b32 %[hi], v71, v65, v69"
         : [lo] "=v"(lo), [hi] "=v"(hi)
         : PIE_SHOUP63_IN(a, w, wsh, nq), [n2q] "s"(n2q), [n1q] "s"(nq)
         : PIE_ASM_CLOB);
@@ -362,18 +363,18 @@ __device__ __forceinline__ void divmod63(u64 a, u64 w, u64 wsh, u64 nq, u64 &quo
     u64 qt;
     const u64 n2q = 2 * nq;
     asm(PIE_SHOUP63_HEAD
-        "v_mad_u64_u32 v[88:89], vcc, v86, %[nql], v[88:89]\n\t"
-        "v_lshl_add_u64 v[92:93], v[88:89], 0, %[n2q]\n\t"
-        "v_ashrrev_i64 v[84:85], 63, v[92:93]\n\t"
-        "v_bfi_b32 v88, v84, v88, v92\n\t"
-        "v_bfi_b32 v89, v84, v89, v93\n\t"
-        "v_lshl_add_u64 v[86:87], v[84:85], 1, v[86:87]\n\t"
-        "v_lshl_add_u64 v[92:93], v[88:89], 0, %[n1q]\n\t"
-        "v_ashrrev_i64 v[84:85], 63, v[92:93]\n\t"
-        "v_bfi_b32 %[lo], v84, v88, v92\n\t"
-        "v_bfi_b32 %[hi], v84, v89, v93\n\t"
-        "v_lshl_add_u64 v[86:87], v[84:85], 0, v[86:87]\n\t"
-        "v_lshl_add_u64 %[qt], v[86:87], 0, 3"
+        "v_mad_u64_u32 v[64:65], vcc, v62, %[nql], v[64:65]\n\t"
+        "v_lshl_add_u64 v[68:69], v[64:65], 0, %[n2q]\n\t"
+        "v_ashrrev_i64 v[60:61], 63, v[68:69]\n\t"
+        "v_bfi_b32 v64, v60, v64, v68\n\t"
+        "v_bfi_b32 v65, v60, v65, v69\n\t"
+        "v_lshl_add_u64 v[62:63], v[60:61], 1, v[62:63]\n\t"
+        "v_lshl_add_u64 v[68:69], v[64:65], 0, %[n1q]\n\t"
+        "v_ashrrev_i64 v[60:61], 63, v[68:69]\n\t"
+        "v_bfi_b32 %[lo], v60, v64, v68\n\t"
+        "v_bfi_b32 %[hi], v60, v65, v69\n\t"
+        "v_lshl_add_u64 v[62:63], v[60:61], 0, v[62:63]\n\t"
+        "v_lshl_add_u64 %[qt], v[62:63], 0, 3"
         : [lo] "=v"(lo), [hi] "=v"(hi), [qt] "=v"(qt)
         : PIE_SHOUP63_IN(a, w, wsh, nq), [n2q] "s"(n2q), [n1q] "s"(nq)
         : PIE_ASM_CLOB);
@@ -385,14 +386,14 @@ __device__ __forceinline__ void divmod63(u64 a, u64 w, u64 wsh, u64 nq, u64 &quo
 __device__ __forceinline__ u64 mulhi_sb(u64 a, u64 b)
 {
     u64 r;
-    asm("v_mul_hi_u32 v84, %[al], %[bl]\n\t"
-        "v_mov_b32 v85, 0\n\t"
-        "v_mad_u64_u32 v[86:87], vcc, %[al], %[bh], v[84:85]\n\t"
-        "v_mad_u64_u32 v[86:87], vcc, %[ah], %[bl], v[86:87]\n\t"
-        "v_mad_u64_u32 v[90:91], s[96:97], %[ah], %[bh], 0\n\t"
-        "v_lshrrev_b64 v[88:89], 32, v[86:87]\n\t"
-        "v_addc_co_u32 v89, vcc, 0, v89, vcc\n\t"
-        "v_lshl_add_u64 %[r], v[90:91], 0, v[88:89]"
+    asm("v_mul_hi_u32 v60, %[al], %[bl]\n\t"
+        "v_mov_b32 v61, 0\n\t"
+        "v_mad_u64_u32 v[62:63], vcc, %[al], %[bh], v[60:61]\n\t"
+        "v_mad_u64_u32 v[62:63], vcc, %[ah], %[bl], v[62:63]\n\t"
+        "v_mad_u64_u32 v[66:67], s[96:97], %[ah], %[bh], 0\n\t"
+        "v_lshrrev_b64 v[64:65], 32, v[62:63]\n\t"
+        "v_addc_co_u32 v65, vcc, 0, v65, vcc\n\t"
+        "v_lshl_add_u64 %[r], v[66:67], 0, v[64:65]"
         : [r] "=v"(r)
         : [al] "v"((u32)a), [ah] "v"((u32)(a >> 32)), [bl] "s"((u32)b), [bh] "s"((u32)(b >> 32))
         : PIE_ASM_CLOB, "s96", "s97");
@@ -411,78 +412,78 @@ __device__ __forceinline__ u64 colacc_reduce(const ColAcc &a, const Mod &m, u64 
     const u64 n2q = 2 * nq, n4q = 4 * nq;
     u64 r;
     if (!W124) {
-        asm("v_lshrrev_b64 v[84:85], 30, %[c0]\n\t"
-            "v_lshl_add_u64 v[84:85], v[84:85], 0, %[c1]\n\t"
-            "v_lshrrev_b64 v[86:87], 30, v[84:85]\n\t"
-            "v_lshl_add_u64 v[86:87], v[86:87], 0, %[c2]\n\t"
-            "v_lshlrev_b64 v[88:89], 1, v[86:87]\n\t"
-            "v_bfe_u32 v92, v84, 29, 1\n\t"
-            "v_and_b32 v90, 0x3fffffff, %[c0l]\n\t"
-            "v_bfe_u32 v91, v84, 2, 28\n\t"
-            "v_or_b32 v88, v88, v92\n\t"
-            "v_lshl_or_b32 v90, v84, 30, v90\n\t"
-            "v_lshl_or_b32 v91, v86, 28, v91\n\t"
-            "v_mul_hi_u32 v92, v88, %[mul]\n\t"
-            "v_mov_b32 v93, 0\n\t"
-            "v_mad_u64_u32 v[92:93], vcc, v88, %[muh], v[92:93]\n\t"
-            "v_mad_u64_u32 v[92:93], vcc, v89, %[mul], v[92:93]\n\t"
-            "v_mad_u64_u32 v[94:95], s[96:97], v89, %[muh], 0\n\t"
-            "v_lshrrev_b64 v[92:93], 32, v[92:93]\n\t"
-            "v_addc_co_u32 v93, vcc, 0, v93, vcc\n\t"
-            "v_lshl_add_u64 v[92:93], v[94:95], 0, v[92:93]\n\t"
-            "v_mad_u64_u32 v[94:95], vcc, v92, %[nqh], 0\n\t"
-            "v_mad_u64_u32 v[94:95], vcc, v93, %[nql], v[94:95]\n\t"
-            "v_add_u32 v91, v91, v94\n\t"
-            "v_mad_u64_u32 v[90:91], vcc, v92, %[nql], v[90:91]\n\t"
-            "v_lshl_add_u64 v[84:85], v[90:91], 0, %[n2q]\n\t"
-            "v_ashrrev_i32 v86, 31, v85\n\t"
-            "v_bfi_b32 v90, v86, v90, v84\n\t"
-            "v_bfi_b32 v91, v86, v91, v85\n\t"
-            "v_lshl_add_u64 v[84:85], v[90:91], 0, %[n1q]\n\t"
-            "v_ashrrev_i32 v86, 31, v85\n\t"
-            "v_and_b32 v88, %[ql], v86\n\t"
-            "v_and_b32 v89, %[qh], v86\n\t"
-            "v_lshl_add_u64 %[r], v[84:85], 0, v[88:89]"
+        asm("v_lshrrev_b64 v[60:61], 30, %[c0]\n\t"
+            "v_lshl_add_u64 v[60:61], v[60:61], 0, %[c1]\n\t"
+            "v_lshrrev_b64 v[62:63], 30, v[60:61]\n\t"
+            "v_lshl_add_u64 v[62:63], v[62:63], 0, %[c2]\n\t"
+            "v_lshlrev_b64 v[64:65], 1, v[62:63]\n\t"
+            "v_bfe_u32 v68, v60, 29, 1\n\t"
+            "v_and_b32 v66, 0x3fffffff, %[c0l]\n\t"
+            "v_bfe_u32 v67, v60, 2, 28\n\t"
+            "v_or_b32 v64, v64, v68\n\t"
+            "v_lshl_or_b32 v66, v60, 30, v66\n\t"
+            "v_lshl_or_b32 v67, v62, 28, v67\n\t"
+            "v_mul_hi_u32 v68, v64, %[mul]\n\t"
+            "v_mov_b32 v69, 0\n\t"
+            "v_mad_u64_u32 v[68:69], vcc, v64, %[muh], v[68:69]\n\t"
+            "v_mad_u64_u32 v[68:69], vcc, v65, %[mul], v[68:69]\n\t"
+            "v_mad_u64_u32 v[70:71], s[96:97], v65, %[muh], 0\n\t"
+            "v_lshrrev_b64 v[68:69], 32, v[68:69]\n\t"
+            "v_addc_co_u32 v69, vcc, 0, v69, vcc\n\t"
+            "v_lshl_add_u64 v[68:69], v[70:71], 0, v[68:69]\n\t"
+            "v_mad_u64_u32 v[70:71], vcc, v68, %[nqh], 0\n\t"
+            "v_mad_u64_u32 v[70:71], vcc, v69, %[nql], v[70:71]\n\t"
+            "v_add_u32 v67, v67, v70\n\t"
+            "v_mad_u64_u32 v[66:67], vcc, v68, %[nql], v[66:67]\n\t"
+            "v_lshl_add_u64 v[60:61], v[66:67], 0, %[n2q]\n\t"
+            "v_ashrrev_i32 v62, 31, v61\n\t"
+            "v_bfi_b32 v66, v62, v66, v60\n\t"
+            "v_bfi_b32 v67, v62, v67, v61\n\t"
+            "v_lshl_add_u64 v[60:61], v[66:67], 0, %[n1q]\n\t"
+            "v_ashrrev_i32 v62, 31, v61\n\t"
+            "v_and_b32 v64, %[ql], v62\n\t"
+            "v_and_b32 v65, %[qh], v62\n\t"
+            "v_lshl_add_u64 %[r], v[60:61], 0, v[64:65]"
             : [r] "=v"(r)
             : [c0] "v"(a.c0), [c1] "v"(a.c1), [c2] "v"(a.c2), [c0l] "v"((u32)a.c0), [mul] "s"((u32)mu), [muh] "s"((u32)(mu >> 32)),
               [nql] "s"((u32)nq), [nqh] "s"((u32)(nq >> 32)), [n2q] "s"(n2q), [n1q] "s"(nq), [ql] "s"((u32)m.q), [qh] "s"((u32)(m.q >> 32))
             : PIE_ASM_CLOB, "s96", "s97");
     } else {
         // z >> 60 = c2' after the normalisation; qhat = 2 floor(zh mu / 2^64); remainder in [0, 7q): one more subtraction
-        asm("v_lshrrev_b64 v[84:85], 30, %[c0]\n\t"
-            "v_lshl_add_u64 v[84:85], v[84:85], 0, %[c1]\n\t"
-            "v_lshrrev_b64 v[88:89], 30, v[84:85]\n\t"
-            "v_lshl_add_u64 v[88:89], v[88:89], 0, %[c2]\n\t"
-            "v_and_b32 v90, 0x3fffffff, %[c0l]\n\t"
-            "v_bfe_u32 v91, v84, 2, 28\n\t"
-            "v_lshl_or_b32 v90, v84, 30, v90\n\t"
-            "v_lshl_or_b32 v91, v88, 28, v91\n\t"
-            "v_mul_hi_u32 v92, v88, %[mul]\n\t"
-            "v_mov_b32 v93, 0\n\t"
-            "v_mad_u64_u32 v[92:93], vcc, v88, %[muh], v[92:93]\n\t"
-            "v_mad_u64_u32 v[92:93], vcc, v89, %[mul], v[92:93]\n\t"
-            "v_mad_u64_u32 v[94:95], s[96:97], v89, %[muh], 0\n\t"
-            "v_lshrrev_b64 v[92:93], 32, v[92:93]\n\t"
-            "v_addc_co_u32 v93, vcc, 0, v93, vcc\n\t"
-            "v_lshl_add_u64 v[92:93], v[94:95], 0, v[92:93]\n\t"
-            "v_lshlrev_b64 v[92:93], 1, v[92:93]\n\t"
-            "v_mad_u64_u32 v[94:95], vcc, v92, %[nqh], 0\n\t"
-            "v_mad_u64_u32 v[94:95], vcc, v93, %[nql], v[94:95]\n\t"
-            "v_add_u32 v91, v91, v94\n\t"
-            "v_mad_u64_u32 v[90:91], vcc, v92, %[nql], v[90:91]\n\t"
-            "v_lshl_add_u64 v[84:85], v[90:91], 0, %[n4q]\n\t"
-            "v_ashrrev_i32 v86, 31, v85\n\t"
-            "v_bfi_b32 v90, v86, v90, v84\n\t"
-            "v_bfi_b32 v91, v86, v91, v85\n\t"
-            "v_lshl_add_u64 v[84:85], v[90:91], 0, %[n2q]\n\t"
-            "v_ashrrev_i32 v86, 31, v85\n\t"
-            "v_bfi_b32 v90, v86, v90, v84\n\t"
-            "v_bfi_b32 v91, v86, v91, v85\n\t"
-            "v_lshl_add_u64 v[84:85], v[90:91], 0, %[n1q]\n\t"
-            "v_ashrrev_i32 v86, 31, v85\n\t"
-            "v_and_b32 v88, %[ql], v86\n\t"
-            "v_and_b32 v89, %[qh], v86\n\t"
-            "v_lshl_add_u64 %[r], v[84:85], 0, v[88:89]"
+        asm("v_lshrrev_b64 v[60:61], 30, %[c0]\n\t"
+            "v_lshl_add_u64 v[60:61], v[60:61], 0, %[c1]\n\t"
+            "v_lshrrev_b64 v[64:65], 30, v[60:61]\n\t"
+            "v_lshl_add_u64 v[64:65], v[64:65], 0, %[c2]\n\t"
+            "v_and_b32 v66, 0x3fffffff, %[c0l]\n\t"
+            "v_bfe_u32 v67, v60, 2, 28\n\t"
+            "v_lshl_or_b32 v66, v60, 30, v66\n\t"
+            "v_lshl_or_b32 v67, v64, 28, v67\n\t"
+            "v_mul_hi_u32 v68, v64, %[mul]\n\t"
+            "v_mov_b32 v69, 0\n\t"
+            "v_mad_u64_u32 v[68:69], vcc, v64, %[muh], v[68:69]\n\t"
+            "v_mad_u64_u32 v[68:69], vcc, v65, %[mul], v[68:69]\n\t"
+            "v_mad_u64_u32 v[70:71], s[96:97], v65, %[muh], 0\n\t"
+            "v_lshrrev_b64 v[68:69], 32, v[68:69]\n\t"
+            "v_addc_co_u32 v69, vcc, 0, v69, vcc\n\t"
+            "v_lshl_add_u64 v[68:69], v[70:71], 0, v[68:69]\n\t"
+            "v_lshlrev_b64 v[68:69], 1, v[68:69]\n\t"
+            "v_mad_u64_u32 v[70:71], vcc, v68, %[nqh], 0\n\t"
+            "v_mad_u64_u32 v[70:71], vcc, v69, %[nql], v[70:71]\n\t"
+            "v_add_u32 v67, v67, v70\n\t"
+            "v_mad_u64_u32 v[66:67], vcc, v68, %[nql], v[66:67]\n\t"
+            "v_lshl_add_u64 v[60:61], v[66:67], 0, %[n4q]\n\t"
+            "v_ashrrev_i32 v62, 31, v61\n\t"
+            "v_bfi_b32 v66, v62, v66, v60\n\t"
+            "v_bfi_b32 v67, v62, v67, v61\n\t"
+            "v_lshl_add_u64 v[60:61], v[66:67], 0, %[n2q]\n\t"
+            "v_ashrrev_i32 v62, 31, v61\n\t"
+            "v_bfi_b32 v66, v62, v66, v60\n\t"
+            "v_bfi_b32 v67, v62, v67, v61\n\t"
+            "v_lshl_add_u64 v[60:61], v[66:67], 0, %[n1q]\n\t"
+            "v_ashrrev_i32 v62, 31, v61\n\t"
+            "v_and_b32 v64, %[ql], v62\n\t"
+            "v_and_b32 v65, %[qh], v62\n\t"
+            "v_lshl_add_u64 %[r], v[60:61], 0, v[64:65]"
             : [r] "=v"(r)
             : [c0] "v"(a.c0), [c1] "v"(a.c1), [c2] "v"(a.c2), [c0l] "v"((u32)a.c0), [mul] "s"((u32)mu), [muh] "s"((u32)(mu >> 32)),
               [nql] "s"((u32)nq), [nqh] "s"((u32)(nq >> 32)), [n4q] "s"(n4q), [n2q] "s"(n2q), [n1q] "s"(nq), [ql] "s"((u32)m.q),
@@ -820,6 +821,12 @@ void launch_scale_pq_expand(const DevConsts *dc, u32 N, u32 L, const u64 *in, si
 // ---------------------------------------------------------------------------------------------
 // Tensor product over QP (row A5 step 4): d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1
 // ---------------------------------------------------------------------------------------------
+// MAD (every modulus in (2^59, 2^60)): the operands arrive lazily reduced (< 8q, from the forward transform); two sign-mask
+// subtractions bring them below 2q < 2^61, the four products go through the carry-free column accumulators (30-bit low halves,
+// <= 31-bit high halves: d1's two products keep every column below 2^63) and one reduction block each (z < 8 q^2 < 2^123):
+// 170 VALU instructions per thread where three 128-bit products with two-word Barrett reductions took 297 -- the kernel
+// was as much bound by them as by its 115 MB of traffic.
+template <bool MAD>
 __global__ void __launch_bounds__(TPB) tensor_kernel(const DevConsts *dc, u32 N, u32 M, const u64 *__restrict__ e,
                                                      u64 *__restrict__ d)
 {
@@ -830,7 +837,24 @@ __global__ void __launch_bounds__(TPB) tensor_kernel(const DevConsts *dc, u32 N,
     const size_t MN = (size_t)M * N;
     const u64 *pe = e + (size_t)bin * 4 * MN + (size_t)a * N + n;
     u64 *pd = d + (size_t)bin * 3 * MN + (size_t)a * N + n;
-    const u64 a0 = pe[0], a1 = pe[MN], b0 = pe[2 * MN], b1 = pe[3 * MN];
+    u64 a0 = pe[0], a1 = pe[MN], b0 = pe[2 * MN], b1 = pe[3 * MN];
+    if (MAD) {
+        const u64 nq = neg_u(m.q), n2q = neg_u(2 * m.q), n4q = neg_u(4 * m.q);
+        a0 = csub_u(csub_u(a0, n4q), n2q), a1 = csub_u(csub_u(a1, n4q), n2q);
+        b0 = csub_u(csub_u(b0, n4q), n2q), b1 = csub_u(csub_u(b1, n4q), n2q);
+        const Split30 sa0 = split30(a0), sa1 = split30(a1), sb0 = split30(b0), sb1 = split30(b1);
+        ColAcc c = {0, 0, 0};
+        colacc_mac(c, sa0, sb0);
+        pd[0] = colacc_reduce<false>(c, m, nq);
+        c = ColAcc{0, 0, 0};
+        colacc_mac(c, sa0, sb1);
+        colacc_mac(c, sa1, sb0);
+        pd[MN] = colacc_reduce<false>(c, m, nq);
+        c = ColAcc{0, 0, 0};
+        colacc_mac(c, sa1, sb1);
+        pd[2 * MN] = colacc_reduce<false>(c, m, nq);
+        return;
+    }
     pd[0] = mulmod(a0, b0, m);
     U128 x = mul128(a0, b1);
     mac128(x, a1, b0);
@@ -840,7 +864,10 @@ __global__ void __launch_bounds__(TPB) tensor_kernel(const DevConsts *dc, u32 N,
 void launch_tensor(const DevConsts *dc, u32 N, u32 M, const u64 *e, u64 *d, u32 nb, hipStream_t st)
 {
     dim3 grid((N + TPB - 1) / TPB, M, nb);
-    hipLaunchKernelGGL(tensor_kernel, grid, dim3(TPB), 0, st, dc, N, M, e, d);
+    if (g_small_moduli)
+        hipLaunchKernelGGL(tensor_kernel<true>, grid, dim3(TPB), 0, st, dc, N, M, e, d);
+    else
+        hipLaunchKernelGGL(tensor_kernel<false>, grid, dim3(TPB), 0, st, dc, N, M, e, d);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1027,8 +1054,13 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restr
     const u64 *key = key0 + (size_t)(bin % key_group) * key_stride;  // one key per position in a group (EvalMerge)
     const Mod m = dc->mod[j];
     const size_t LN = (size_t)L * N;
-    U128 acc[2][2];
+    u64x2 mk;
+    if (mask) mk = *reinterpret_cast<const u64x2 *>(mask + (size_t)bin * LN + (size_t)j * N + n);
+    const u32 po = TILE ? 0 : (out_map ? out_map[n] : n);
+    u64x2 res[2];
     if (MAD) {
+        // column accumulators end to end: the L products, then d01 (it may arrive unnormalised, < 2^63, from the forward
+        // transform) into column 0 -- (L + 8) 2^60 < 2^64 -- and one reduction block; the mask product likewise
         ColAcc a[2][2] = {{{0, 0, 0}, {0, 0, 0}}, {{0, 0, 0}, {0, 0, 0}}};
         for (u32 i = 0; i < L; i++) {
             const u64x2 d = *reinterpret_cast<const u64x2 *>(dig + (((size_t)bin * L + i) * L + j) * N + n);
@@ -1040,11 +1072,24 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restr
             colacc_mac(a[1][0], dx, split30(k1.x));
             colacc_mac(a[1][1], dy, split30(k1.y));
         }
+        const u64 nq = 0 - m.q;
 #pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int e = 0; e < 2; e++) acc[c][e] = colacc_value(a[c][e]);
+        for (int c = 0; c < 2; c++) {
+            const u64x2 s = *reinterpret_cast<const u64x2 *>(d01 + (size_t)bin * stride01 + (size_t)c * LN + (size_t)j * N + n);
+            a[c][0].c0 += s.x;
+            a[c][1].c0 += s.y;
+            res[c].x = colacc_reduce<false>(a[c][0], m, nq);
+            res[c].y = colacc_reduce<false>(a[c][1], m, nq);
+            if (mask) {
+                ColAcc p0 = {0, 0, 0}, p1 = {0, 0, 0};
+                colacc_mac(p0, split30(res[c].x), split30(mk.x));
+                colacc_mac(p1, split30(res[c].y), split30(mk.y));
+                res[c].x = colacc_reduce<false>(p0, m, nq);
+                res[c].y = colacc_reduce<false>(p1, m, nq);
+            }
+        }
     } else {
+        U128 acc[2][2];
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
@@ -1058,23 +1103,23 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restr
             mac128(acc[1][0], d.x, k1.x);
             mac128(acc[1][1], d.y, k1.y);
         }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const u64x2 s = *reinterpret_cast<const u64x2 *>(d01 + (size_t)bin * stride01 + (size_t)c * LN + (size_t)j * N + n);
+            // d01 joins the sum before the reduction: it may arrive unnormalised (< 2^63) from the forward transform
+            add128(acc[c][0], U128{s.x, 0});
+            add128(acc[c][1], U128{s.y, 0});
+            res[c].x = reduce128(acc[c][0], m);
+            res[c].y = reduce128(acc[c][1], m);
+            if (mask) {
+                res[c].x = mulmod(res[c].x, mk.x, m);
+                res[c].y = mulmod(res[c].y, mk.y, m);
+            }
+        }
     }
-    u64x2 mk;
-    if (mask) mk = *reinterpret_cast<const u64x2 *>(mask + (size_t)bin * LN + (size_t)j * N + n);
-    const u32 po = TILE ? 0 : (out_map ? out_map[n] : n);
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-        const u64x2 s = *reinterpret_cast<const u64x2 *>(d01 + (size_t)bin * stride01 + (size_t)c * LN + (size_t)j * N + n);
-        u64x2 r;
-        // d01 joins the sum before the reduction: it may arrive unnormalised (< 2^63) from the forward transform
-        add128(acc[c][0], U128{s.x, 0});
-        add128(acc[c][1], U128{s.y, 0});
-        r.x = MAD ? reduce123(acc[c][0], m) : reduce128(acc[c][0], m);  // L <= 7 products + a 63-bit term
-        r.y = MAD ? reduce123(acc[c][1], m) : reduce128(acc[c][1], m);
-        if (mask) {
-            r.x = mulmod(r.x, mk.x, m);
-            r.y = mulmod(r.y, mk.y, m);
-        }
+        const u64x2 r = res[c];
         if (TILE)
             s_tile[c][KP * (threadIdx.x % TT) + threadIdx.x / TT] = r;  // standard offset inside the tile: KP (tau - tau0) + k
         else

@@ -102,6 +102,7 @@ def _worker_queries(rank, world, port, b, q):
 
         db, masks, evk = rl(rng, (K, b, E)), rl(rng, (b,)), rl(rng, (L, 2))
         lo, hi = shard.bin_slice(b, rank, world)
+        seeds = shard.shared_seeds()      # drawn on rank 0, the same on every rank (what binSlice databases must be built with)
         split = K * E * 2 * L * N
         qb = shard.QueryBroadcast(split + 2 * L * N, "cpu", src=0, kind="broadcast")
         qrng = np.random.default_rng(1000 + rank)   # rank 0's stream is the only one that is used
@@ -128,7 +129,7 @@ def _worker_queries(rank, world, port, b, q):
                 bmax = shard.max_bins(b, world)
                 rows = [out0[r * bmax: r * bmax + (shard.bin_slice(b, r, world)[1] - shard.bin_slice(b, r, world)[0])] for r in range(world)]
                 ok = ok and bool((torch.cat(rows).numpy() == want).all())
-        q.put((rank, ok, (lo, hi)))
+        q.put((rank, ok, seeds))
     except Exception as e:  # report instead of hanging the parent on q.get
         import traceback
         q.put((rank, False, repr(e) + traceback.format_exc()))
@@ -149,6 +150,7 @@ def test_query_distribution_then_gather(world, b):
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
+    assert len({tuple(sd) for _, _, sd in res}) == 1 and len(res[0][2]) == 3, res   # one set of (evict, shuffle, mask) seeds
 
 
 def test_bin_slices_partition():
