@@ -111,7 +111,7 @@ class QueryBroadcast:
         self.chunk = -(-words // self.world)
         padded = self.chunk * self.world
         self.d_in = [torch.zeros(padded, dtype=torch.int64, device=self.device) for _ in range(2)]
-        self.d_mine = torch.zeros(self.chunk, dtype=torch.int64, device=self.device) if kind == "scatter_gather" else None
+        self.mine = {}   # scatter_gather: this rank's 1/world of the array, one buffer per device the array is distributed on
         self.used = [False, False]
         self.h_in = None
         if self.host_staged and self.cuda:
@@ -136,10 +136,13 @@ class QueryBroadcast:
     def _distribute(self, buf):
         if self.world == 1:
             return
-        if self.kind == "scatter_gather" and not self.host_staged:   # (gloo: plain broadcast between host buffers)
+        if self.kind == "scatter_gather":
+            mine = self.mine.get(buf.device)
+            if mine is None:
+                mine = self.mine[buf.device] = torch.zeros(self.chunk, dtype=torch.int64, device=buf.device)
             parts = list(buf.view(self.world, self.chunk).unbind(0)) if self.rank == self.src else None
-            dist.scatter(self.d_mine, scatter_list=parts, src=self.src, group=self.group)
-            dist.all_gather_into_tensor(buf, self.d_mine, group=self.group)
+            dist.scatter(mine, scatter_list=parts, src=self.src, group=self.group)
+            dist.all_gather_into_tensor(buf, mine, group=self.group)
         else:
             dist.broadcast(buf, src=self.src, group=self.group)
 

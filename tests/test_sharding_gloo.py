@@ -81,7 +81,7 @@ def test_gather_matches_unsharded(world, b):
     assert max(hi - lo for lo, hi in slices) - min(hi - lo for lo, hi in slices) <= 1
 
 
-def _worker_queries(rank, world, port, b, q):
+def _worker_queries(rank, world, port, b, q, kind="broadcast"):
     """the sharded server's step on CPU: rank 0 alone knows the query; QueryBroadcast hands it to every rank, every rank
     evaluates its bin layers (the oracle stands in for the GPU), the results are gathered to rank 0"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -104,7 +104,7 @@ def _worker_queries(rank, world, port, b, q):
         lo, hi = shard.bin_slice(b, rank, world)
         seeds = shard.shared_seeds()      # drawn on rank 0, the same on every rank (what binSlice databases must be built with)
         split = K * E * 2 * L * N
-        qb = shard.QueryBroadcast(split + 2 * L * N, "cpu", src=0, kind="broadcast")
+        qb = shard.QueryBroadcast(split + 2 * L * N, "cpu", src=0, kind=kind)
         qrng = np.random.default_rng(1000 + rank)   # rank 0's stream is the only one that is used
         ok = True
         for i in range(3):
@@ -137,13 +137,14 @@ def _worker_queries(rank, world, port, b, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,b", [(2, 5), (4, 6)])
-def test_query_distribution_then_gather(world, b):
-    """three consecutive, different queries that only rank 0 knows"""
+@pytest.mark.parametrize("world,b,kind", [(2, 5, "broadcast"), (4, 6, "broadcast"), (3, 5, "scatter_gather"), (4, 6, "scatter_gather")])
+def test_query_distribution_then_gather(world, b, kind):
+    """three consecutive, different queries that only rank 0 knows; both ways of distributing them (a plain broadcast; a scatter
+    of 1/world to every rank followed by an all-gather -- world = 3 does not divide the array: padded chunks)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_queries, args=(r, world, port, b, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_queries, args=(r, world, port, b, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]
