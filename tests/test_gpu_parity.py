@@ -795,6 +795,44 @@ def test_staged_query_upload(ob, pie):
     cc.close()
 
 
+@pytest.mark.parametrize("N,L", [(8192, 3), (16384, 4), (32768, 6)])
+def test_extreme_residues_through_run(ob, pie, N, L):
+    """residues 0 and q - 1 in every array that enters run() (index matrix, minus element, database, masks, key): the boundary
+    cases of the lazy ranges in the butterfly blocks, of the quotient estimates (shoup63 / divmod63) and of the column
+    accumulators, on the three transform geometries (one 2^13 slice per limb; two folded 2^13; two folded 2^14)"""
+    t, K, E, b = T32, 2, 3, 2
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(N)
+    q = o.moduli[:L]
+
+    def rl(shape):
+        a = rand_limbs(rng, q, shape, N)
+        for i in range(L):
+            a[..., i, 0:64] = q[i] - np.uint64(1)
+            a[..., i, 64:128] = 0
+            a[..., i, N // 2:N // 2 + 32] = q[i] - np.uint64(1)     # the folded partner positions too
+            a[..., i, N - 32:] = q[i] - np.uint64(1)
+        return a
+    idx, minus = rl((K, E, 2)), rl((2,))
+    db, masks, evk = rl((K, b, E)), rl((b,)), rl((L, 2))
+    cc.load_relin_key(evk)
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    op.setMinusCompareElement(minus)
+    op.setIndex(idx)
+    op.run()
+    assert (op.getResultList() == o.pie_run(idx, minus, db, masks, evk)).all()
+    # ... and with every residue at q - 1
+    allmax = lambda shape: np.broadcast_to((q - np.uint64(1))[:, None], shape + (L, N)).copy()
+    idx, minus, db, masks = allmax((K, E, 2)), allmax((2,)), allmax((K, b, E)), allmax((b,))
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    op.setMinusCompareElement(minus)
+    op.setIndex(idx)
+    op.run()
+    assert (op.getResultList() == o.pie_run(idx, minus, db, masks, evk)).all()
+    cc.close()
+
+
 # ---- the caller of the hot path as its own process, talking the reference's framing ---------------------------------------
 @pytest.mark.parametrize("shape", ["small", "C3"])
 def test_two_process_psi_over_the_wire(ob, pie, tmp_path, shape):
