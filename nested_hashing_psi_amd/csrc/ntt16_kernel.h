@@ -69,7 +69,7 @@ __device__ __forceinline__ Tw make_tw(u64x2 p)
 struct ModC {
     u32 nql, nqh;  // 2^64 - q
     u64 nq4;       // 2^64 - 4q
-    u64 q4p1;      // 4q + 1
+    u64 q4;        // 4q
 };
 
 // ---- the 60-bit lazy butterfly as hand-scheduled instruction blocks ---------------------------------------------------------
@@ -79,10 +79,11 @@ struct ModC {
 // (derivation in kernels_ntt_fast.hip).  Why assembly blocks (tools/gen_ntt16_bfly.py writes them): hipcc narrows multiplier
 // ops whose high half is dead to v_mul_lo_u32 (half the rate), lowers conditional subtractions to compare + select chains
 // through VCC (a VALU write of VCC or an SGPR needs two wait states before a VALU may read it on gfx950) and pads every short
-// asm statement with s_nop.  20-21 (forward) / 21-22 (inverse) instructions per butterfly, 9 of them on the multiplier, 11 / 13
-// fixed scratch registers at the top of the 128-register budget, no VCC reads (carry-outs are discarded into VCC); conditional
-// subtraction x in [0, 2m) -> [0, m) as t = x - m followed by a select on the sign of t (v_bfi / v_and under an
-// arithmetic-shift mask).
+// asm statement with s_nop.  19-20 instructions per butterfly in both directions, 9 of them on the multiplier, 11 fixed scratch
+// registers at the top of the 128-register budget.  Conditional subtraction x in [0, 2m) -> [0, m) as t = x - m followed by a
+// select on the sign of t (v_bfi_b32 under an arithmetic-shift mask); the two 64-bit differences (u + 4q - v forward,
+// a + 4q - b inverse) as v_sub_co_u32 / v_subb_co_u32 with two independent instructions between the halves (the wait
+// states a VALU read of VCC needs after a VALU write); every other carry-out is discarded into VCC.
 #define NTT16_S(x) "s"(x)
 #define NTT16_V(x) "v"(x)
 #include "ntt16_bfly.inc"
@@ -92,21 +93,28 @@ struct ModC {
 // SC: the twiddles are wave-uniform (SGPR operands).  H2: the block takes 2 sh as an operand (t.sh2) instead of doubling the
 // high word of the multiplicand itself -- one instruction fewer; worth it where a twiddle serves several butterflies (every
 // wave-uniform one: the doubling is a scalar instruction; per-lane ones of the stages with fewer twiddles than butterflies).
-// The inverse block has that form for wave-uniform twiddles only (tools/gen_ntt16_bfly.py); the inverse kernel does not use
-// it: the extra scalar operands push it into scalar-register spills (measured: 96.2 vs 95.7 us per 2048 slices).
-template <bool INV, bool SC, bool H2 = SC && !INV>
+#ifndef NTT16_INV_H2
+#define NTT16_INV_H2 1
+#endif
+template <bool INV, bool SC, bool H2 = SC && (!INV || NTT16_INV_H2)>
 __device__ __forceinline__ void bfly(u64 &x0, u64 &y0, const Tw &t0, const ModC &m)
 {
     const u64 a0 = x0, b0 = y0;
-    u64 ao0, bo0;
     if (INV) {
+        u32 aol0, aoh0;
+        u64 bo0;
         if (SC && H2)
-            NTT16_GS1HS();
+            NTT16_GS1H(NTT16_S);
         else if (SC)
             NTT16_GS1(NTT16_S);
+        else if (H2)
+            NTT16_GS1H(NTT16_V);
         else
             NTT16_GS1(NTT16_V);
+        x0 = ((u64)aoh0 << 32) | aol0, y0 = bo0;
     } else {
+        u64 ao0;
+        u32 bol0, boh0;
         if (SC && H2)
             NTT16_CT1H(NTT16_S);
         else if (SC)
@@ -115,8 +123,8 @@ __device__ __forceinline__ void bfly(u64 &x0, u64 &y0, const Tw &t0, const ModC 
             NTT16_CT1H(NTT16_V);
         else
             NTT16_CT1(NTT16_V);
+        x0 = ao0, y0 = ((u64)boh0 << 32) | bol0;
     }
-    x0 = ao0, y0 = bo0;
 }
 // two butterflies (call sites pair them; one block each: see tools/gen_ntt16_bfly.py on why they are not interleaved)
 template <bool INV, bool SC, bool H2 = SC && !INV>
@@ -317,7 +325,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
         const u64 q = dcs->mod[mod].q;
         const u64 q2 = 2 * q, q4 = 4 * q;
         ModC mc;
-        mc.nql = (u32)(0 - q), mc.nqh = (u32)((0 - q) >> 32), mc.nq4 = 0 - q4, mc.q4p1 = q4 + 1;
+        mc.nql = (u32)(0 - q), mc.nqh = (u32)((0 - q) >> 32), mc.nq4 = 0 - q4, mc.q4 = q4;
         const TwS tw = (TwS)uniform_addr(a.twp + ((size_t)mod * 2 + (INV ? 1 : 0)) * a.N);
         const u64x2 *__restrict__ twk = a.twk + (((size_t)mod * 2 + (INV ? 1 : 0)) << a.s0) * TWK_PER_SLICE + (size_t)blk * TWK_PER_SLICE;
         const u64x2 *__restrict__ tw3 = twk + (size_t)w * 15 * 16;                 // [slot 0..14][16 a]

@@ -17,30 +17,29 @@ import os
 OUT = os.environ.get("NTT16_BFLY_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nested_hashing_psi_amd", "csrc", "ntt16_bfly.inc")
 
 
-NREG = {False: 11, True: 13}  # fixed VGPRs per stream: forward (CT), inverse (GS)
+NREG = {False: 11, True: 11}  # fixed VGPRs per stream: forward (CT), inverse (GS)
 
 
 class Regs:
     """Fixed registers of stream i.  Lifetimes allow these overlays (see the instruction lists):
-    both: U over T (the select / t writes in place); the sign mask in QE's low register until qe is written
-    CT:   N over CR (cr is dead once qe exists), T6 over QE (computed after the last use of qe)
-    GS:   N over CR (~b is dead before m1), the early a + 4q + 1 over QE, the masked 4q over D (d is dead by then)"""
+    CT:   u over t (the select writes in place); the sign mask in QE's low register until qe is written; u + 4q over QE (after
+          the last use of qe)
+    GS:   a + 4q over QE (dead once d exists); s = a + b over ACC and t = s - 4q over C (both dead after the select, before
+          the first product); the sign mask in X until 2 dh is written"""
     def __init__(self, i, gs):
         n = NREG[gs]
         self.n = n
         self.base = 128 - n * (i + 1) - int(os.environ.get('NTT16_BASE_SHIFT', '0'))
         b = self.base
-        self.X = b           # 2 bh
-        self.M = b           # sign mask
-        self.T = b + 1       # t = x - 4q
-        self.U = self.T      # CT: u (in place); GS: s, then t in place
+        self.X = b           # 2 bh (CT) / sign mask, then 2 dh (GS)
+        self.T = b + 1       # CT: t = a - 4q, then u in place
+        self.U = self.T
+        self.D = b + 1       # GS: d = a - b + 4q
         self.CR = b + 3      # m1 / cr / cr >> 31
-        self.N = self.CR     # ~v (CT, after qe) / ~b (GS, before m1)
         self.QE = b + 5
-        self.T6 = self.QE    # CT: u + 4q + 1 (after the last use of qe); GS: a + 4q + 1 (before qe)
+        self.T6 = self.QE    # CT: u + 4q (after the last use of qe); GS: a + 4q (before qe)
         self.ACC = b + 7     # acc, then v
         self.C = b + 9
-        self.D = b + 11      # GS only: d = a - b + 4q
 
     def all(self):
         return range(self.base, self.base + self.n)
@@ -54,6 +53,11 @@ def v(r):
     return "v%d" % r
 
 
+# A 64-bit difference is v_sub_co_u32 + v_subb_co_u32 through VCC (gfx950 has no 64-bit vector subtraction; the alternative,
+# x + ~y + 1, is two v_not_b32 and a v_lshl_add_u64).  A VALU instruction that reads VCC needs two wait states after the VALU
+# write of VCC: two independent instructions that leave VCC alone sit between the halves (the multiplier instructions discard
+# their carry-out into VCC, so none of them may).  The halves of an asm operand cannot be named, so a result that is produced
+# in halves is two 32-bit outputs (the register coalescer makes them a pair).
 def ct_stream(i, h2=False):
     r = Regs(i, False)
     o = lambda name: "%%[%s%d]" % (name, i)
@@ -79,64 +83,45 @@ def ct_stream(i, h2=False):
         ("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.QE), v(r.X), o("sh"), p(r.CR))),  # qe = 2 bh sh + (cr >> 31)
         "v_mad_u64_u32 %s, vcc, %s, %%[nql], %s" % (p(r.ACC), v(r.QE), p(r.ACC)),     # acc += qe_lo nq_lo
         "v_mad_u64_u32 %s, vcc, %s, %%[nqh], %s" % (p(r.C), v(r.QE), p(r.C)),         # c += qe_lo nq_hi
-        "v_mad_u64_u32 %s, vcc, %s, %%[nql], %s" % (p(r.C), v(r.QE + 1), p(r.C)),     # c += qe_hi nq_lo
-        "v_lshl_add_u64 %s, %s, 0, %%[q4p1]" % (p(r.T6), p(r.U)),                     # u + 4q + 1   (over qe)
-        "v_not_b32 %s, %s" % (v(r.N), v(r.ACC)),
+        "v_mad_u64_u32 %s, vcc, %s, %%[nql], %s" % (p(r.C), v(r.QE + 1), p(r.C)),     # c += qe_hi nq_lo: the last read of an input
+        "v_lshl_add_u64 %s, %s, 0, %%[q4]" % (p(r.T6), p(r.U)),                       # u + 4q   (over qe)
+        "v_sub_co_u32 %s, vcc, %s, %s" % (o("bol"), v(r.T6), v(r.ACC)),               # b' = u + 4q - v, low half
         "v_add_u32 %s, %s, %s" % (v(r.ACC + 1), v(r.ACC + 1), v(r.C)),                # v = acc + (c << 32)
-        "v_not_b32 %s, %s" % (v(r.N + 1), v(r.ACC + 1)),
         "v_lshl_add_u64 %s, %s, 0, %s" % (o("ao"), p(r.U), p(r.ACC)),                 # a' = u + v
-        "v_lshl_add_u64 %s, %s, 0, %s" % (o("bo"), p(r.T6), p(r.N)),                  # b' = u + 4q + 1 + ~v
+        "v_subb_co_u32 %s, vcc, %s, %s, vcc" % (o("boh"), v(r.T6 + 1), v(r.ACC + 1)), # b', high half
     ]
 
 
 def gs_stream(i, h2=False):
-    """h2: wave-uniform twiddles only (SGPR operands), with 2 sh as an operand of its own.  No per-lane input is read after the
-    first six instructions then, so a' may be written early, d's registers stay intact for the quotient estimate, and the
-    doubling of dh goes away: 21 instructions."""
+    """h2: 2 sh is an operand of its own (wave-uniform twiddles: the doubling is a scalar instruction)"""
     r = Regs(i, True)
     o = lambda name: "%%[%s%d]" % (name, i)
     dl, dh = v(r.D), v(r.D + 1)
-    head = [
-        "v_not_b32 %s, %s" % (v(r.N), o("bl")),
-        "v_not_b32 %s, %s" % (v(r.N + 1), o("bh")),
-        "v_lshl_add_u64 %s, %s, 0, %%[q4p1]" % (p(r.T6), o("a")),                     # a + 4q + 1   (over qe, dead here)
-        "v_lshl_add_u64 %s, %s, 0, %s" % (p(r.U), o("a"), o("b")),                    # s = a + b
-        "v_lshl_add_u64 %s, %s, 0, %s" % (p(r.D), p(r.T6), p(r.N)),                   # d = a - b + 4q
-        "v_lshl_add_u64 %s, %s, 0, %%[nq4]" % (p(r.T), p(r.U)),                       # t = s - 4q   (in place)
+    s, t, m = r.ACC, r.C, r.X
+    return [
+        "v_lshl_add_u64 %s, %s, 0, %%[q4]" % (p(r.T6), o("a")),                       # a + 4q   (over qe)
+        "v_lshl_add_u64 %s, %s, 0, %s" % (p(s), o("a"), o("b")),                      # s = a + b   (over acc)
+        "v_sub_co_u32 %s, vcc, %s, %s" % (dl, v(r.T6), o("bl")),                      # d = a + 4q - b, low half
+        "v_lshl_add_u64 %s, %s, 0, %%[nq4]" % (p(t), p(s)),                           # t = s - 4q   (over c)
+        "v_ashrrev_i32 %s, 31, %s" % (v(m), v(t + 1)),                                # all ones iff t < 0
+        "v_subb_co_u32 %s, vcc, %s, %s, vcc" % (dh, v(r.T6 + 1), o("bh")),            # d, high half
+        "v_bfi_b32 %s, %s, %s, %s" % (o("aol"), v(m), v(s), v(t)),                    # a' = t < 0 ? s : t   (early-clobber outputs:
+        "v_bfi_b32 %s, %s, %s, %s" % (o("aoh"), v(m), v(s + 1), v(t + 1)),            #  the twiddles are read below)
         "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.ACC), dl, o("wl")),
         "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.C), dl, o("wh")),
-        "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.CR), dl, o("sh")),                  # (over ~b, dead)
+        "v_mad_u64_u32 %s, vcc, %s, %s, 0" % (p(r.CR), dl, o("sh")),
         "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.CR), dh, o("sl"), p(r.CR)),
         "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.C), dh, o("wl"), p(r.C)),
-    ]
-    tail = [
+    ] + ([] if h2 else [
+        "v_lshlrev_b32 %s, 1, %s" % (v(r.X), dh),
+    ]) + [
+        "v_lshrrev_b64 %s, 31, %s" % (p(r.CR), p(r.CR)),
+        ("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.QE), dh, o("sh2"), p(r.CR))) if h2 else
+        ("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.QE), v(r.X), o("sh"), p(r.CR))),  # the last read of a per-lane twiddle
         "v_mad_u64_u32 %s, vcc, %s, %%[nqh], %s" % (p(r.C), v(r.QE), p(r.C)),
         "v_mad_u64_u32 %s, vcc, %s, %%[nql], %s" % (p(r.C), v(r.QE + 1), p(r.C)),
         "v_add_u32 %s, %s, %s" % (v(r.ACC + 1), v(r.ACC + 1), v(r.C)),                # dl wl + (c << 32)
-    ]
-    last = "v_mad_u64_u32 %s, vcc, %s, %%[nql], %s" % (o("bo"), v(r.QE), p(r.ACC))   # b' = d w: the last product lands in the output
-    if h2:
-        m = r.X
-        return head + [
-            "v_ashrrev_i32 %s, 31, %s" % (v(m), v(r.T + 1)),
-            "v_and_b32 %s, %%[q4l], %s" % (v(r.QE), v(m)),                            # 4q where t < 0   (qe's registers, until qe exists)
-            "v_and_b32 %s, %%[q4h], %s" % (v(r.QE + 1), v(m)),
-            "v_lshl_add_u64 %s, %s, 0, %s" % (o("ao"), p(r.T), p(r.QE)),              # a' = t < 0 ? s : t
-            "v_lshrrev_b64 %s, 31, %s" % (p(r.CR), p(r.CR)),
-            "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.QE), dh, o("sh2"), p(r.CR)),
-        ] + tail + [last]
-    m = r.T6  # sign mask: in the register of a + 4q + 1 (dead once d exists), until qe is written
-    return head + [
-        # four 2-cycle instructions in a row (see ct_stream); d is dead after the first of them and takes the masked 4q
-        "v_lshlrev_b32 %s, 1, %s" % (v(r.X), dh),
-        "v_ashrrev_i32 %s, 31, %s" % (v(m), v(r.T + 1)),
-        "v_and_b32 %s, %%[q4l], %s" % (dl, v(m)),                                     # 4q where t < 0
-        "v_and_b32 %s, %%[q4h], %s" % (dh, v(m)),
-        "v_lshrrev_b64 %s, 31, %s" % (p(r.CR), p(r.CR)),
-        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (p(r.QE), v(r.X), o("sh"), p(r.CR)),    # the last read of a per-lane twiddle
-    ] + tail + [
-        "v_lshl_add_u64 %s, %s, 0, %s" % (o("ao"), p(r.T), p(r.D)),                   # a' = t < 0 ? s : t
-        last,
+        "v_mad_u64_u32 %s, vcc, %s, %%[nql], %s" % (o("bo"), v(r.QE), p(r.ACC)),      # b' = d w: the last product lands in the output
     ]
 
 
@@ -150,18 +135,27 @@ def interleave(streams):
 
 
 def emit(name, gs, nb, h2=False):
-    """h2: the twiddle's doubled high Shoup word is an operand (t.sh2); the inverse form takes wave-uniform twiddles only"""
+    """h2: the twiddle's doubled high Shoup word is an operand (t.sh2)"""
     lines = interleave([(gs_stream if gs else ct_stream)(i, h2) for i in range(nb)])
     body = " \\\n".join('        "%s\\n\\t"' % ln for ln in lines)
-    # no early-clobber: every per-lane input is read before the first output is written (checked below), so outputs may reuse
-    # input registers
-    first_out = min(k for k, ln in enumerate(lines) if "%[ao" in ln or "%[bo" in ln)
-    tw_names = () if (gs and h2) else ("wl", "wh", "sl", "sh", "sh2")   # (scalar registers in the uniform-only form)
-    vgpr_inputs = ["%%[%s%d]" % (nm, i) for nm in ("a", "b", "al", "ah", "bl", "bh") + tw_names for i in range(nb)]
+    # forward: no early-clobber -- every input is read before the first output is written (checked below), so outputs may reuse
+    # input registers.  inverse: a' is written before the twiddles are read -> its two halves are early-clobber outputs.
+    early = ("aol", "aoh") if gs else ()
+    late = ("bo",) if gs else ("ao", "bol", "boh")
+    first_out = min(k for k, ln in enumerate(lines) if any("%%[%s" % nm in ln for nm in late))
+    vgpr_inputs = ["%%[%s%d]" % (nm, i) for nm in ("a", "b", "al", "ah", "bl", "bh", "wl", "wh", "sl", "sh", "sh2") for i in range(nb)]
     for ln in lines[first_out + 1:]:
         assert not any(op + "," in ln + "," or ln.endswith(op) for op in vgpr_inputs), "input read after an output was written: " + ln
-    outs = ", ".join('[ao%d] "=v"(ao%d), [bo%d] "=v"(bo%d)' % (i, i, i, i) for i in range(nb))
-    twc = "NTT16_S" if (gs and h2) else "TWC"
+    # VCC: written by the low half of a difference, read by its high half two or more instructions later, untouched in between
+    for k, ln in enumerate(lines):
+        if ln.startswith("v_sub_co_u32"):
+            j = next(j for j in range(k + 1, len(lines)) if lines[j].startswith("v_subb_co_u32"))
+            assert j - k - 1 >= 2 and not any("vcc" in x for x in lines[k + 1:j]), "VCC hazard: " + ln
+    if gs:
+        outs = ", ".join('[aol%d] "=&v"(aol%d), [aoh%d] "=&v"(aoh%d), [bo%d] "=v"(bo%d)' % ((i,) * 6) for i in range(nb))
+    else:
+        outs = ", ".join('[ao%d] "=v"(ao%d), [bol%d] "=v"(bol%d), [boh%d] "=v"(boh%d)' % ((i,) * 6) for i in range(nb))
+    twc = "TWC"
     ins = []
     for i in range(nb):
         if gs:
@@ -172,24 +166,20 @@ def emit(name, gs, nb, h2=False):
         ins.append('[wl%d] %s(t%d.wl), [wh%d] %s(t%d.wh), [sl%d] %s(t%d.sl), [sh%d] %s(t%d.sh)' % (i, twc, i, i, twc, i, i, twc, i, i, twc, i))
         if h2:
             ins.append('[sh2%d] %s(t%d.sh2)' % (i, twc, i))
-    ins.append('[nql] "s"(m.nql), [nqh] "s"(m.nqh), [nq4] "s"(m.nq4), [q4p1] "s"(m.q4p1)')
-    if gs:
-        ins.append('[q4l] "s"((u32)(m.q4p1 - 1)), [q4h] "s"((u32)((m.q4p1 - 1) >> 32))')
+    ins.append('[nql] "s"(m.nql), [nqh] "s"(m.nqh), [nq4] "s"(m.nq4), [q4] "s"(m.q4)')
     clob = ['"vcc"'] + ['"v%d"' % x for i in range(nb) for x in Regs(i, gs).all()]
-    args = "" if (gs and h2) else "TWC"
-    return ("#define %s(%s) \\\n    asm( \\\n%s \\\n        : %s \\\n        : %s \\\n        : %s)\n"
-            % (name, args, body, outs, ", \\\n          ".join(ins), ", ".join(clob)))
+    return ("#define %s(TWC) \\\n    asm( \\\n%s \\\n        : %s \\\n        : %s \\\n        : %s)\n"
+            % (name, body, outs, ", \\\n          ".join(ins), ", ".join(clob)))
 
 
 def main():
     text = ("// ntt16_bfly.inc -- GENERATED by tools/gen_ntt16_bfly.py; do not edit.  See that script and ntt16_kernel.h.\n"
-            "// NTT16_{CT,GS}1(TWC): one butterfly on (a0, b0, t0) -> (ao0, bo0);\n"
-            "// TWC = NTT16_S (wave-uniform twiddles, SGPR operands) or NTT16_V (per-lane twiddles); m = ModC.\n"
-            "// NTT16_CT1H(TWC) / NTT16_GS1HS(): 2 sh is an operand of its own (t0.sh2) -- one instruction fewer; the inverse form is\n"
-            "// for wave-uniform twiddles only.\n")
+            "// NTT16_CT1(TWC): one forward butterfly on (a0, b0, t0) -> (ao0, {bol0, boh0}); NTT16_GS1(TWC): one inverse butterfly\n"
+            "// -> ({aol0, aoh0}, bo0).  TWC = NTT16_S (wave-uniform twiddles, SGPR operands) or NTT16_V (per-lane twiddles); m = ModC.\n"
+            "// NTT16_CT1H(TWC) / NTT16_GS1H(TWC): 2 sh is an operand of its own (t0.sh2) -- one instruction fewer.\n")
     # one butterfly per block: measured, a wave issues at most every other VALU slot whatever its instruction-level parallelism
     # (interleaving two butterflies per block changed nothing but the register count), so parallelism comes from waves
-    text += emit("NTT16_CT1", False, 1) + emit("NTT16_GS1", True, 1) + emit("NTT16_CT1H", False, 1, True) + emit("NTT16_GS1HS", True, 1, True)
+    text += emit("NTT16_CT1", False, 1) + emit("NTT16_GS1", True, 1) + emit("NTT16_CT1H", False, 1, True) + emit("NTT16_GS1H", True, 1, True)
     with open(OUT, "w") as f:
         f.write(text)
     print("wrote", OUT)

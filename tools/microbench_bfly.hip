@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) probe(u64 *out, u64 q, u64x2 twv)
     u64 x[16];
     for (int k = 0; k < 16; k++) x[k] = (threadIdx.x * 977 + k * 131 + 5) % q;
     ModC mc;
-    mc.nql = (u32)(0 - q), mc.nqh = (u32)((0 - q) >> 32), mc.nq4 = 0 - 4 * q, mc.q4p1 = 4 * q + 1;
+    mc.nql = (u32)(0 - q), mc.nqh = (u32)((0 - q) >> 32), mc.nq4 = 0 - 4 * q, mc.q4 = 4 * q;
     u64x2 tv = twv;
     if (!SC) tv.x += threadIdx.x & 1;  // per-lane twiddle: VGPR operands
     const Tw t = make_tw(tv);
