@@ -275,11 +275,24 @@ inline u32 lane_to_std(u32 p) { return lane_to_std_t(p, T); }
 // LDS addresses are written as (one per-thread base) + (compile-time constant): phi is additive over multiples of 32, and a
 // base the compiler has to keep per row ends up in scratch memory.  Global addresses: uniform row base + one lane offset.
 #define NTT16_FENCE() __builtin_amdgcn_sched_barrier(0)
-// Wave priority falls as a wave advances through the passes of a slice.  The SIMD arbiter serves the highest priority, then the
-// oldest wave: with equal priorities the older of the two waves a workgroup has on each SIMD runs at full speed, the younger
-// on what is left, and the workgroup's barriers then wait for the younger half (measured: 9000 of 32000 cycles per slice).
-// With the priority tied to progress the wave that is behind is served first and all eight arrive together.
+// Wave priority falls as a wave advances from one workgroup barrier to the next.  The SIMD arbiter serves the highest
+// priority, then the oldest wave: with equal priorities the older of the waves a workgroup has on each SIMD runs at full speed,
+// the younger on what is left, and the workgroup's barriers then wait for the younger ones (measured: 9000 of 32000 cycles per
+// slice).  With the priority tied to progress the wave that is behind is served first and all arrive together.  Forward: the
+// barrier sits after pass 1, so pass 2 is the start of the cycle and pass 1 of the NEXT slice its end (lowest priority; its
+// loads are issued at the highest, they are a handful of instructions): 2048 slices 88.2 -> 82.5 us against "pass 1 highest",
+// the run's ragged launches unchanged (profiles/r03/ntt16_lab_wave_priorities.txt).  Inverse: barriers after pass 4' and pass 2'.
 #define NTT16_PASS_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#ifndef NTT16_PF
+#define NTT16_PF 3, 0, 3, 2, 1   // forward: loads, pass 1, pass 2, pass 3, pass 4
+#endif
+#ifndef NTT16_PI
+#define NTT16_PI 3, 3, 2, 1, 0   // inverse: loads, pass 4', pass 3', pass 2', pass 1'
+#endif
+#define NTT16_PRIO_PICK_(i, a0, a1, a2, a3, a4) ((i) == 0 ? (a0) : (i) == 1 ? (a1) : (i) == 2 ? (a2) : (i) == 3 ? (a3) : (a4))
+#define NTT16_PRIO_PICK(i, ...) NTT16_PRIO_PICK_(i, __VA_ARGS__)
+#define NTT16_PRIO_F(i) NTT16_PASS_PRIO(NTT16_PRIO_PICK(i, NTT16_PF))
+#define NTT16_PRIO_I(i) NTT16_PASS_PRIO(NTT16_PRIO_PICK(i, NTT16_PI))
 
 // LIFT (forward only): the launch may carry key-switch digit items (Args::lift_first); a separate instantiation, so that the
 // plain forward transform does not pay for the lift's registers
@@ -341,7 +354,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
 
         if (!INV) {
             NTT16_STAMP(0);
-            NTT16_PASS_PRIO(3);
+            NTT16_PRIO_F(0);
             // ---- pass 1: rows r = 0..7 (bits 12..10) of the column pair -------------------------------------------------
             if (lift) {
                 // equal-width primes (q_i < 2 q_j for every pair: the host checks): a conditional subtraction reduces a residue
@@ -388,6 +401,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
 #pragma unroll
                 for (int r = 0; r < (int)R; r++) row_get<CPT>(x, r, g + 1024 * r + coff);
             }
+            NTT16_PRIO_F(1);
 #pragma unroll
             for (int s = 0; s < (int)LOGR; s++) {
                 const int d = (int)(R >> 1) >> s;
@@ -408,7 +422,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
             __syncthreads();
             NTT16_STAMP(4);
             // ---- pass 2: e = 1024 w + 64 k + l, stages 3..6 -----------------------------------------------------------------
-            NTT16_PASS_PRIO(2);
+            NTT16_PRIO_F(2);
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = p2[68 * k];
 #pragma unroll
@@ -431,7 +445,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
             NTT16_STAMP(5);
             wave_sync();
             // ---- pass 3: e = 1024 w + 64 a + 4 k + c, stages 7..10 -------------------------------------------------------
-            NTT16_PASS_PRIO(1);
+            NTT16_PRIO_F(3);
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = p3[4 * k + 2 * (k >> 3)];
             NTT16_LOAD3(t9, 2);
@@ -465,7 +479,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
             NTT16_STAMP(6);
             wave_sync();
             // ---- pass 4: e = 1024 w + 16 l + k, stages 11, 12 ---------------------------------------------------------------
-            NTT16_PASS_PRIO(0);
+            NTT16_PRIO_F(4);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const u64x2 v = *reinterpret_cast<const u64x2 *>(p4 + 2 * j);
@@ -506,7 +520,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
             NTT16_STAMP(8);
         } else {
             // ---- input: 16 contiguous coefficients per thread -------------------------------------------------------------
-            NTT16_PASS_PRIO(3);
+            NTT16_PRIO_I(0);
             NTT16_LOAD4(t12, 4, 8);
             if (a.flags & F_STD_IN) {
                 // standard order: coalesced rows through LDS
@@ -544,6 +558,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                 }
             }
             NTT16_FENCE();
+            NTT16_PRIO_I(1);
             // ---- pass 4': stages 12, 11 ----------------------------------------------------------------------------------------
             NTT16_LOAD4(t11, 0, 4);
             NTT16_FENCE();
@@ -569,7 +584,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
             }
             wave_sync();
             // ---- pass 3': stages 10..7 -----------------------------------------------------------------------------------------
-            NTT16_PASS_PRIO(2);
+            NTT16_PRIO_I(2);
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = p3[4 * k + 2 * (k >> 3)];
             NTT16_LOAD3(t9, 2);
@@ -600,7 +615,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
             for (int k = 0; k < 16; k++) p3[4 * k + 2 * (k >> 3)] = x[k];
             wave_sync();
             // ---- pass 2': stages 6..3 ------------------------------------------------------------------------------------------
-            NTT16_PASS_PRIO(1);
+            NTT16_PRIO_I(3);
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = p2[68 * k];
 #pragma unroll
@@ -618,7 +633,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
             for (int k = 0; k < 16; k++) p2[68 * k] = x[k];
             __syncthreads();
             // ---- pass 1': the top LOGR stages, stored straight to HBM ------------------------------------------------------------------
-            NTT16_PASS_PRIO(0);
+            NTT16_PRIO_I(4);
 #pragma unroll
             for (int r = 0; r < (int)R; r++) row_get<CPT>(x, r, p1 + 1088 * r);
 #pragma unroll

@@ -12,7 +12,7 @@
 #ifdef LAB_STAMPS
 // cycle stamps of the second slice of block 0, one row per wave: -DLAB_STAMPS
 #include <stdint.h>
-__device__ unsigned long long g_stamps[8 * 16];
+__device__ unsigned long long g_stamps[16 * 16];
 #define NTT16_STAMP(i)                                                                                       \
     do {                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -197,11 +197,11 @@ int main(int argc, char **argv)
         a.lift_first = ~0u;
         for (int rep = 0; rep < 400; rep++) hipLaunchKernelGGL((ntt16_kernel_t<LAB_LOGNS, false>), dim3(grid), dim3(T), lds, 0, a);
         CK(hipDeviceSynchronize());
-        unsigned long long st[8 * 16];
+        unsigned long long st[16 * 16];
         CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st)));
         static const char *names[9] = {"load", "pass1", "barA", "ldsW", "barB", "rd+pass2", "pass3", "pass4", "store"};
-        printf("forward, %u blocks (%u/2 per CU): cycles per phase of the second slice (s_memtime ticks)\n", grid, grid / 128);
-        for (int w = 0; w < 8; w++) {
+        printf("forward, %u blocks (%.1f per CU): cycles per phase of the second slice (s_memtime ticks)\n", grid, grid / 256.0);
+        for (int w = 0; w < (int)LG::W; w++) {
             printf("  wave %d:", w);
             for (int i = 1; i <= 8; i++) printf(" %s %llu", names[i], st[w * 16 + i] - st[w * 16 + i - 1]);
             printf("  | total %llu cycles in %.2f us -> %.2f GHz\n", st[w * 16 + 8] - st[w * 16 + 0], (st[w * 16 + 10] - st[w * 16 + 9]) / 100.0,
