@@ -312,6 +312,7 @@ def time_slots(ops, steps, warmup, sync, repeats=7, warm_seconds=0.1):
 
 
 PROJECTION_IN_FLIGHT = 3
+DEFAULT_BATCH = 1
 
 
 def projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, steps, warmup):
@@ -477,6 +478,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="queries in flight: query slots (own stream + workspace, one shared database: piehip_attach_database) that "
                          "run() round-robin.  0 = default (3: one hardware queue each on a runtime with four), 1 = one query at a time")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="queries per run() (piehip_set_query_batch): a step is one run() over that many queries, each with its own "
+                         "inputs and results; stage A reads the database once per batch.  0 = default")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams run() spreads the bin layers over (0 = library default, 1 = serial: every kernel alone on the GPU)")
     ap.add_argument("--collective", default="auto", choices=["auto", "gather", "all_gather"],
@@ -570,6 +574,22 @@ def main():
         slots += make_query_slots(torch, pie, cc, op, (N, L, t, K, E), in_flight, device, local_rank, gen, run_streams)
     elif in_flight > 1:   # a rank without bin layers still takes part in every slot's collective
         slots += [(None, None, torch.cuda.Stream(device), None, None) for _ in range(1, in_flight)]
+    # Queries per run().  A server with several clients waiting evaluates their queries together: stage A streams the packed
+    # database (3/4 of its traffic) once for the batch, and every later launch carries `batch` times the ciphertexts.
+    batch = max(1, args.batch or DEFAULT_BATCH)
+    if use_dist or args.graph or op is None:
+        batch = 1
+    extra_inputs = []
+    if batch > 1:
+        for c_, o_, st_, i_, m_ in slots:
+            o_.setQueryBatch(batch)
+            for q_ in range(1, batch):
+                iq = uniform_limbs(torch, (K, E, 2), cc.q, N, device, gen)
+                mq = uniform_limbs(torch, (2,), cc.q, N, device, gen)
+                extra_inputs.append((iq, mq))
+                o_.setIndexDevice(iq.data_ptr(), query=q_)
+                o_.setMinusCompareElementDevice(mq.data_ptr(), query=q_)
+        torch.cuda.synchronize(device)
     ct_words = 2 * L * N
     rg = None
     rgs = []
@@ -735,8 +755,11 @@ def main():
                         "measured": "HIP events around every launch, median of %d serial passes of run() after a warm-up (one stream; the "
                                     "timed region uses %s)" % (len(passes), "%d queue(s) per run(), %d queries in flight" % (run_streams or 2, in_flight))}
 
+    if batch > 1:   # the legs below take one query per run()
+        for c_, o_, st_, i_, m_ in slots:
+            o_.setQueryBatch(1)
     if rank == 0:
-        value = b_total / (ms_per_step * 1e-3)
+        value = batch * b_total / (ms_per_step * 1e-3)
         cname = "C4 (C3's bin layers over %d GPUs)" % world if (world > 1 and scaling == "strong" and args.config == "C3") else args.config
         line = {
             "metric": "server PIE ciphertexts/sec", "value": value, "unit": "ciphertexts/s", "n_gpus": world, "steps": args.steps,
@@ -746,24 +769,26 @@ def main():
                       "of warm-up" % (len(blocks), args.steps, args.warmup, args.warm_seconds),
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%s: BatchedFHEHIPPIE::run(), N=%d, %d RNS primes (60-bit), t=%d, |S|=2^%d |C|=2^%d, k=%d e=%d (B=%d slots), "
-                                   "K=%d E=%d, b=%d bin layers in all, %d on rank 0; %d ct x pt MACs + %d ct x ct (HPS + BV relin) + %d mask mults per step"
+                                   "K=%d E=%d, b=%d bin layers in all, %d on rank 0; %d quer%s per step: %d ct x pt MACs + %d ct x ct (HPS + BV relin) + %d mask mults per step"
                                    % (cname, N, L, t, cfg["S"].bit_length() - 1, cfg["C"].bit_length() - 1, cfg["k"], cfg["e"], B, K, E,
-                                      b_total, b_local, b_total * K * E, b_total * (K - 1), b_total),
-                       "result_ciphertexts_per_step": b_total, "parallelism": "bins%d" % world,
+                                      b_total, b_local, batch, "y" if batch == 1 else "ies", batch * b_total * K * E, batch * b_total * (K - 1),
+                                      batch * b_total),
+                       "result_ciphertexts_per_step": batch * b_total, "queries_per_step": batch, "parallelism": "bins%d" % world,
                        "collective": ("%s: %s of the query from rank 0 (%s), %s of results"
                                       % ("gloo (rehearsal)" if args.rehearse_on_one_gpu else "rccl", qdist_kind or "no distribution",
                                          args.query_source, args.collective)) if use_dist else "none",
                        "query_distribution_s": qdist_times,
                        "queries_in_flight": in_flight},
-            "mac_per_s": b_total * K * E / (ms_per_step * 1e-3), "mul_per_s": b_total * (K - 1) / (ms_per_step * 1e-3),
+            "mac_per_s": batch * b_total * K * E / (ms_per_step * 1e-3), "mul_per_s": batch * b_total * (K - 1) / (ms_per_step * 1e-3),
+            "ms_per_query": ms_per_step / batch, "queries_per_step": batch,
             "queries_in_flight": in_flight, "run_streams": run_streams or 2, "hipgraph": bool(args.graph),
             **({"rehearsal": "all ranks on one GPU, gloo gather: not a measurement"} if args.rehearse_on_one_gpu else {}),
             # whole run(): algorithmic bytes of the REFERENCE's unfused schedule over the measured time.  Not HBM
             # utilisation: this build's schedule moves fewer bytes than the formula counts (fused stage A, 95 instead of 111
             # limb transforms per multiplication), so the fraction says how far the run is from the 8 TB/s bound of that schedule
             "run_roofline": {"alg_bytes_per_run_per_gpu": alg_bytes_run(dict(cfg, b=b_local)),
-                             "ref_schedule_GBps_per_gpu": alg_bytes_run(dict(cfg, b=b_local)) / (ms_per_step * 1e-3) / 1e9,
-                             "ref_schedule_bytes_over_time_frac": alg_bytes_run(dict(cfg, b=b_local)) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "ref_schedule_GBps_per_gpu": batch * alg_bytes_run(dict(cfg, b=b_local)) / (ms_per_step * 1e-3) / 1e9,
+                             "ref_schedule_bytes_over_time_frac": batch * alg_bytes_run(dict(cfg, b=b_local)) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "note": "bytes of the reference's unfused schedule / measured time / 8 TB/s; not measured HBM traffic"},
             "roofline": roofline, "kernels": kernels,
         }

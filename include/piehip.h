@@ -189,7 +189,25 @@ int piehip_set_graph(piehip_handle h, int on);
  * handles read those buffers on streams of their own.  Loading a database into `h` itself returns it to a private copy
  * (load_relin_key is refused while attached). */
 int piehip_attach_database(piehip_handle h, piehip_handle owner);
-/* getResultList (BatchedFHEHIPPIE.hpp:35-38): out[b][2][L][N] */
+/* Query batches: one run() evaluates nq (1 .. 8) queries -- each with its own index matrix and minus element -- against the
+ * handle's database.  The reference operator takes one query per run() (BatchedFHEHIPPIE.hpp:40-48, .cpp:88-129); a server
+ * with several clients waiting hands them over together: stage A then reads every database plaintext once for the batch
+ * instead of once per query (the database is 3/4 of that stage's traffic), and every later launch carries nq times as many
+ * ciphertexts.  Each query's results are bit-identical to its own run().
+ *   piehip_set_query_batch   sizes the workspace for nq queries per run() (default 1; may be called before or after the database
+ *                            is loaded; synchronises the handle's stream)
+ *   piehip_set_*_q           inputs of query q < nq (q = 0: the plain setters above)
+ *   results                  piehip_run / piehip_run_into / piehip_get_results then use rows [b][nq][2][L][N]: the nq result
+ *                            ciphertexts of a bin layer are adjacent
+ * With nq > 1 the host-buffer entry points (piehip_run_host*, piehip_stage_*, piehip_host_buffers) and the captured graph
+ * are not available (PIEHIP_ESTATE / eager launches). */
+int piehip_set_query_batch(piehip_handle h, uint32_t nq);
+int piehip_get_query_batch(piehip_handle h, uint32_t *nq);
+int piehip_set_index_q(piehip_handle h, uint32_t q, const uint64_t *idx /*[K][E][2][L][N]*/);
+int piehip_set_minus_q(piehip_handle h, uint32_t q, const uint64_t *minus /*[2][L][N]*/);
+int piehip_set_index_device_q(piehip_handle h, uint32_t q, const void *d_idx);
+int piehip_set_minus_device_q(piehip_handle h, uint32_t q, const void *d_minus);
+/* getResultList (BatchedFHEHIPPIE.hpp:35-38): out[b][2][L][N] (out[b][nq][2][L][N] for a query batch) */
 int piehip_get_results(piehip_handle h, uint64_t *out);
 /* device address of the result buffer [b][2][L][N] (valid until destroy); for the RCCL gather */
 int piehip_results_device(piehip_handle h, void **d_out);

@@ -54,6 +54,12 @@ SYMBOLS = {
     "piehip_set_run_streams": (C.c_int, [C.c_void_p, C.c_uint32]),
     "piehip_set_graph": (C.c_int, [C.c_void_p, C.c_int]),
     "piehip_attach_database": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "piehip_set_query_batch": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "piehip_get_query_batch": (C.c_int, [C.c_void_p, u32p]),
+    "piehip_set_index_q": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
+    "piehip_set_minus_q": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
+    "piehip_set_index_device_q": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "piehip_set_minus_device_q": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "piehip_get_results": (C.c_int, [C.c_void_p, u64p]),
     "piehip_results_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "piehip_copy_results_device": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -98,8 +98,19 @@ void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_
 // small_moduli: every RNS modulus is < 2^60 (enables the v_mad_u64_u32 column-accumulator kernel)
 // bstride: bin-layer count of the database array db[K][bstride][E][L][N] when only b <= bstride layers (starting at the
 // layer db points to) are evaluated; 0 = b.  h0, hn: only the inner hash functions [h0, h0 + hn) (hn = 0: all from h0)
+// nq, q: the accumulators are row q of a batch of nq queries, acc[b][nq][K][2][L][N] (nq = 1: the layout above)
 void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
-                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride = 0, u32 h0 = 0, u32 hn = 0);
+                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride = 0, u32 h0 = 0, u32 hn = 0, u32 nq = 1,
+                    u32 q = 0);
+// Stage A of a batch of nq <= PIEHIP_MAX_BATCH queries on one database: acc[b][nq][K][2][L][N]; the database is read once for
+// the batch where the column-accumulator kernel applies (small_moduli, nq <= 4)
+static const u32 STAGE_A_MAX_QUERIES = 8;
+struct StageAQueries {
+    const u64 *idx[STAGE_A_MAX_QUERIES];
+    const u64 *minus[STAGE_A_MAX_QUERIES];
+};
+void launch_stage_a_batch(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const StageAQueries &qs, u32 nq, const u64 *db,
+                          u64 *acc, hipStream_t st, bool small_moduli, u32 bstride = 0, u32 h0 = 0, u32 hn = 0);
 
 // (per-host-thread switch, set from the context before its launches: all Q and P moduli lie in (2^59, 2^60), which lets
 // the base-conversion and key-switch kernels use the carry-free v_mad_u64_u32 column accumulators and one-word Barrett)
@@ -132,11 +143,12 @@ void launch_digits(const DevConsts *dc, u32 N, u32 L, const u64 *d2, size_t stri
 // out[bin][c][j] = (d01[bin][c][j] + sum_i dig[bin][i][j] (.) key[i][c][j]) (.) mask[bin][j]   (mask may be null)
 // out_map (may be null): coefficient n of the result is written to position out_map[n] (lane order -> standard)
 // key_group > 1: ciphertext `bin` uses key + (bin % key_group) * key_stride (EvalMerge: one rotation key per position)
+// mask_div > 1: ciphertext `bin` takes mask[bin / mask_div] (a query batch: mask_div queries per bin layer)
 // sigma_T != 0: out_map is the lane order of a transform with sigma_T threads per slice and sigma_kp coefficient pairs per thread
 // (16: kernels_ntt_fast.hip, 8: ntt16_kernel.h); stores then go through an LDS tile
 void launch_relin_mac(const DevConsts *dc, u32 N, u32 L, const u64 *d01, size_t stride01, const u64 *dig, const u64 *key,
                       const u64 *mask, u64 *out, u32 nb, hipStream_t st, const u32 *out_map = nullptr, size_t key_stride = 0,
-                      u32 key_group = 1, u32 sigma_T = 0, u32 sigma_kp = 16);
+                      u32 key_group = 1, u32 sigma_T = 0, u32 sigma_kp = 16, u32 mask_div = 1);
 // rotation-based PIE (FHEHIPPIE.cpp:61-77), see kernels_pie.hip
 void launch_bcast_mul_plain(const DevConsts *dc, u32 N, u32 L, const u64 *x, size_t xs, u32 group, const u64 *pt, size_t ps_outer,
                             size_t ps_inner, u64 *out, u32 nct, hipStream_t st);
@@ -146,8 +158,9 @@ void launch_sum_mul_plain(const DevConsts *dc, u32 N, u32 L, const u64 *x, u32 g
                           size_t out_stride, u32 ngroups, hipStream_t st);
 // element-wise helpers on nct ciphertexts [nct][2][L][N]
 void launch_ct_add(const DevConsts *dc, u32 N, u32 L, const u64 *x, const u64 *y, u64 *out, u32 nct, hipStream_t st);
+// (pt_div > 1: ciphertext i takes plaintext i / pt_div)
 void launch_ct_mul_plain(const DevConsts *dc, u32 N, u32 L, const u64 *x, const u64 *pt, size_t pt_stride, u64 *out,
-                         u32 nct, hipStream_t st);
+                         u32 nct, hipStream_t st, u32 pt_div = 1);
 // out[r][p] = in[r][map[p]] for nrows limbs
 void launch_permute(u32 N, const u64 *in, const u32 *map, u64 *out, u32 nrows, hipStream_t st);
 // packed encoding: slots[npt][B] -> u[npt][N] residues mod t at their EVALUATION positions

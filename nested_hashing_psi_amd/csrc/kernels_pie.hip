@@ -6,6 +6,8 @@
 // from one DevConsts block.  Reference call sites: BatchedFHEHIPPIE.cpp:101-127.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "kernels.hpp"
 #include "madasm.h"
 
@@ -30,10 +32,32 @@ void set_small_moduli(bool v) { g_small_moduli = v; }
 // ---------------------------------------------------------------------------------------------
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
+// Block -> (coefficient block, limb, inner hash function, group of bin layers).  The `groups` blocks of one tile read the same
+// index-ciphertext words (and different database words): they should run on the same XCD, one after the other, so that all
+// but the first take the index words from that XCD's L2.  Workgroups go to the eight XCDs round-robin by their linear id, so
+// a one-dimensional grid is cut as id = 8 * slot + xcd, slot = tile_of_this_xcd * groups + group.  (With the layer group in
+// blockIdx.z the blocks of a tile were `tiles` apart in dispatch order: every group fetched the index matrix from HBM again.)
+struct StageATile {
+    u32 bx, l, hz, grp;
+};
+__device__ __forceinline__ bool stage_a_tile(u32 nx, u32 L, u32 tiles, u32 groups, StageATile &t)
+{
+    const u32 id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    t.grp = slot % groups;
+    const u32 tile = (slot / groups) * 8 + xcd;
+    if (tile >= tiles) return false;
+    t.bx = tile % nx;
+    t.l = (tile / nx) % L;
+    t.hz = tile / (nx * L);
+    return true;
+}
+static dim3 stage_a_grid(u32 nx, u32 L, u32 hn, u32 groups) { return dim3(8 * ((nx * L * hn + 7) / 8) * groups); }
+
 template <int BPT>
 __global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
                                                       const u64 *__restrict__ idx, const u64 *__restrict__ minus,
-                                                      const u64 *__restrict__ db, u64 *__restrict__ acc, u32 bstride, u32 h0)
+                                                      const u64 *__restrict__ db, u64 *__restrict__ acc, u32 bstride, u32 h0,
+                                                      u32 nq, u32 q)
 {
     const u32 n = 2 * (blockIdx.x * TPB + threadIdx.x);
     const u32 l = blockIdx.y;
@@ -80,7 +104,7 @@ __global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *__restric
     const u64x2 m1 = *reinterpret_cast<const u64x2 *>(minus + LN + (size_t)l * N + n);
 #pragma unroll
     for (int t = 0; t < BPT; t++) {
-        u64 *po = acc + (((size_t)(beta0 + t) * K + h) * 2) * LN + (size_t)l * N + n;
+        u64 *po = acc + ((((size_t)(beta0 + t) * nq + q) * K + h) * 2) * LN + (size_t)l * N + n;
         u64x2 r0, r1;
         r0.x = addmod(reduce128(a[t][0][0], m), m0.x, m.q);
         r0.y = addmod(reduce128(a[t][0][1], m), m0.y, m.q);
@@ -105,7 +129,8 @@ __device__ __forceinline__ u64 colacc_reduce(const ColAcc &a, const Mod &m, u64 
 template <int BPT>
 __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
                                                           const u64 *__restrict__ idx, const u64 *__restrict__ minus,
-                                                          const u64 *__restrict__ db, u64 *__restrict__ acc, u32 bstride, u32 h0)
+                                                          const u64 *__restrict__ db, u64 *__restrict__ acc, u32 bstride, u32 h0,
+                                                          u32 nq, u32 q)
 {
     const u32 nl = threadIdx.x;  // lane part of the coefficient index: every stream is a uniform base plus this
     const u32 n = blockIdx.x * TPB + nl;
@@ -163,26 +188,115 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
     }
 #pragma unroll
     for (int t = 0; t < BPT; t++) {
-        u64 *po = acc + (((size_t)(beta0 + t) * K + h) * 2) * LN + (size_t)l * N + n;
+        u64 *po = acc + ((((size_t)(beta0 + t) * nq + q) * K + h) * 2) * LN + (size_t)l * N + n;
 #pragma unroll
         for (int c = 0; c < 2; c++)
             po[(size_t)c * LN] = addmod(colacc_reduce<true>(a[t][c], m, 0 - m.q), minus[(size_t)c * LN + (size_t)l * N + n], m.q);
     }
 }
 
+// A batch of Q queries against one database (piehip_set_query_batch): the thread holds the accumulators of Q queries x BPT bin
+// layers, so a database word is loaded once for the whole batch -- the database is 196 of the 253 MiB stage A moves for one
+// query at the headline shape -- and an index-ciphertext word once per BPT layers as before.  A term is 2 Q + BPT loads for
+// 2 Q BPT multiply-accumulates (one query, seven layers: 9 for 14; two queries, four layers: 8 for 16).
+// acc rows: [bin layer][query][K][2][L][N] (the product chain treats (layer, query) as one batch index).
+// 27-31 us per query at the headline shape against 46-49 for one query per launch; what bounds it then is issue time plus
+// memory latency at three waves per SIMD, not HBM bytes -- profiles/r03/stage_a_batch_microbench.txt, with the cuts that were
+// tried on top (index words shared through L1 or LDS) and dropped.
+template <int BPT, int Q, int DEPTH>
+__global__ void __launch_bounds__(TPB) stage_a_mad_batch_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
+                                                                StageAQueries qs, const u64 *__restrict__ db, u64 *__restrict__ acc,
+                                                                u32 bstride, u32 h0, u32 nq, u32 q0, u32 tiles)
+{
+    StageATile tl;
+    if (!stage_a_tile((N + TPB - 1) / TPB, L, tiles, b / BPT, tl)) return;
+    const u32 nl = threadIdx.x, n0 = tl.bx * TPB, l = tl.l, h = h0 + tl.hz, beta0 = tl.grp * BPT;
+    const u32 n = n0 + nl;
+    if (n >= N) return;
+    const Mod m = dc->mod[l];
+    const size_t LN = (size_t)L * N;
+    const size_t ioff = ((size_t)h * E) * 2 * LN + (size_t)l * N + n0;
+    const u64 *pd = db + (((size_t)h * bstride + beta0) * E) * LN + (size_t)l * N + n0;
+    const size_t bin_stride = (size_t)E * LN;
+    ColAcc a[Q][BPT][2];
+#pragma unroll
+    for (int q = 0; q < Q; q++)
+#pragma unroll
+        for (int t = 0; t < BPT; t++) a[q][t][0] = a[q][t][1] = ColAcc{0, 0, 0};
+    auto load_term = [&](u32 j, u64 (&vi)[Q][2], u64 (&vd)[BPT]) {
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const u64 *pij = qs.idx[q] + ioff + (size_t)j * 2 * LN;
+            vi[q][0] = pij[nl];
+            vi[q][1] = (pij + LN)[nl];
+        }
+        const u64 *pdj = pd + (size_t)j * LN;
+#pragma unroll
+        for (int t = 0; t < BPT; t++) vd[t] = __builtin_nontemporal_load(pdj + (size_t)t * bin_stride + nl);
+    };
+    u64 qiv[DEPTH][Q][2], qdv[DEPTH][BPT];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if ((u32)d < E) load_term(d, qiv[d], qdv[d]);
+    auto term = [&](u32 j, u64 (&vi)[Q][2], u64 (&vd)[BPT]) {
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const Split30 i0 = split30(vi[q][0]), i1 = split30(vi[q][1]);
+#pragma unroll
+            for (int t = 0; t < BPT; t++) colacc_mac2(a[q][t][0], a[q][t][1], i0, i1, vd[t]);
+        }
+        if (j + DEPTH < E) load_term(j + DEPTH, vi, vd);
+        if ((j % COLACC_MAX_TERMS) == COLACC_MAX_TERMS - 1 && j + 1 < E) {
+#pragma unroll
+            for (int q = 0; q < Q; q++)
+#pragma unroll
+                for (int t = 0; t < BPT; t++) colacc_carry(a[q][t][0]), colacc_carry(a[q][t][1]);
+        }
+        if ((j % COLACC_MAX_TOTAL) == COLACC_MAX_TOTAL - 1 && j + 1 < E) {
+#pragma unroll
+            for (int q = 0; q < Q; q++)
+#pragma unroll
+                for (int t = 0; t < BPT; t++)
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        const u64 r = reduce124(colacc_value(a[q][t][c]), m);
+                        a[q][t][c] = ColAcc{r & 0x3FFFFFFFull, r >> 30, 0};
+                    }
+        }
+    };
+    for (u32 j = 0; j < E; j += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++)
+            if (j + d < E) term(j + d, qiv[d], qdv[d]);
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        u64 mi[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) mi[c] = qs.minus[q][(size_t)c * LN + (size_t)l * N + n];
+#pragma unroll
+        for (int t = 0; t < BPT; t++) {
+            u64 *po = acc + ((((size_t)(beta0 + t) * nq + q0 + q) * K + h) * 2) * LN + (size_t)l * N + n;
+#pragma unroll
+            for (int c = 0; c < 2; c++) po[(size_t)c * LN] = addmod(colacc_reduce<true>(a[q][t][c], m, 0 - m.q), mi[c], m.q);
+        }
+    }
+}
+
 // one launch over b bin layers whose count is a multiple of the per-thread layer count `bpt`
 static void launch_stage_a_uniform(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
-                                   const u64 *db, u64 *acc, hipStream_t st, bool mad, u32 bstride, u32 h0, u32 hn, int bpt)
+                                   const u64 *db, u64 *acc, hipStream_t st, bool mad, u32 bstride, u32 h0, u32 hn, int bpt, u32 nq,
+                                   u32 q)
 {
     const int cpt = mad ? 1 : 2;
     dim3 grid((N / cpt + TPB - 1) / TPB, L, hn * (b / bpt));
 #define SA(B_)                                                                                                       \
     do {                                                                                                             \
-        if (mad) hipLaunchKernelGGL(stage_a_mad_kernel<B_>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0); \
-        else hipLaunchKernelGGL(stage_a_kernel<B_>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0);  \
+        if (mad) hipLaunchKernelGGL(stage_a_mad_kernel<B_>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0, nq, q); \
+        else hipLaunchKernelGGL(stage_a_kernel<B_>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0, nq, q);  \
     } while (0)
     switch (bpt) {
-        case 8: hipLaunchKernelGGL(stage_a_kernel<8>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0); break;
+        case 8: hipLaunchKernelGGL(stage_a_kernel<8>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0, nq, q); break;
         case 7: SA(7); break;
         case 6: SA(6); break;
         case 5: SA(5); break;
@@ -195,10 +309,11 @@ static void launch_stage_a_uniform(const DevConsts *dc, u32 N, u32 L, u32 K, u32
 }
 
 void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
-                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride, u32 h0, u32 hn)
+                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride, u32 h0, u32 hn, u32 nq, u32 q)
 {
     if (!bstride) bstride = b;
     if (!hn) hn = K - h0;
+    if (!nq) nq = 1;
     const bool mad = small_moduli;
     const u32 cap = mad ? 7 : 8;
     // Bin layers per thread: a thread re-reads the two index-ciphertext limbs once per group of layers, so groups should be
@@ -214,13 +329,71 @@ void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, cons
     if (b <= cap) bpt = b;
     const size_t LN = (size_t)L * N;
     if (bpt) {
-        launch_stage_a_uniform(dc, N, L, K, b, E, idx, minus, db, acc, st, mad, bstride, h0, hn, (int)bpt);
+        launch_stage_a_uniform(dc, N, L, K, b, E, idx, minus, db, acc, st, mad, bstride, h0, hn, (int)bpt, nq, q);
         return;
     }
     const u32 full = (b / cap) * cap, rest = b - full;
-    launch_stage_a_uniform(dc, N, L, K, full, E, idx, minus, db, acc, st, mad, bstride, h0, hn, (int)cap);
-    launch_stage_a_uniform(dc, N, L, K, rest, E, idx, minus, db + (size_t)full * E * LN, acc + (size_t)full * K * 2 * LN, st, mad,
-                           bstride, h0, hn, (int)rest);
+    launch_stage_a_uniform(dc, N, L, K, full, E, idx, minus, db, acc, st, mad, bstride, h0, hn, (int)cap, nq, q);
+    launch_stage_a_uniform(dc, N, L, K, rest, E, idx, minus, db + (size_t)full * E * LN, acc + (size_t)full * nq * K * 2 * LN, st, mad,
+                           bstride, h0, hn, (int)rest, nq, q);
+}
+
+// Stage A of a query batch: acc[b][nq][K][2][L][N].  Column-accumulator kernel (every modulus < 2^60): groups of two to four
+// queries per launch (plus one launch for the layers left over by the per-thread layer count), each reading the database once;
+// otherwise one launch series per query.
+template <int Q, int BPT>
+static void launch_stage_a_batch_qb(const DevConsts *dc, u32 N, u32 L, u32 K, u32 nb, u32 E, const StageAQueries &qs, const u64 *db,
+                                    u64 *acc, hipStream_t st, u32 bstride, u32 h0, u32 hn, u32 nq, u32 q0)
+{
+    const u32 nx = (N + TPB - 1) / TPB;
+    constexpr int DEPTH = Q == 4 ? 2 : 3;  // terms in flight behind the one being accumulated (profiles/r03/stage_a_batch_microbench.txt)
+    hipLaunchKernelGGL((stage_a_mad_batch_kernel<BPT, Q, DEPTH>), stage_a_grid(nx, L, hn, nb / BPT), dim3(TPB), 0, st, dc, N, L, K, nb, E,
+                       qs, db, acc, bstride, h0, nq, q0, nx * L * hn);
+}
+template <int Q>
+static void launch_stage_a_batch_q(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const StageAQueries &qs, const u64 *db,
+                                   u64 *acc, hipStream_t st, u32 bstride, u32 h0, u32 hn, u32 nq, u32 q0)
+{
+    constexpr u32 cap = Q == 2 ? 4 : 2;  // bin layers per thread: Q * cap accumulator pairs (eight at most)
+    const size_t LN = (size_t)L * N;
+    auto go = [&](u32 nb, u32 bpt, const u64 *dbp, u64 *accp) {
+        if constexpr (cap >= 4) {
+            if (bpt == 4) return launch_stage_a_batch_qb<Q, 4>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0);
+            if (bpt == 3) return launch_stage_a_batch_qb<Q, 3>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0);
+        }
+        if (bpt == 2) return launch_stage_a_batch_qb<Q, 2>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0);
+        return launch_stage_a_batch_qb<Q, 1>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0);
+    };
+    u32 bpt = 0;
+    for (u32 c = cap; c >= 2; c--)
+        if (b % c == 0) {
+            bpt = c;
+            break;
+        }
+    if (b <= cap) bpt = b;
+    if (bpt) return go(b, bpt, db, acc);
+    const u32 full = (b / cap) * cap, rest = b - full;
+    go(full, cap, db, acc);
+    go(rest, rest, db + (size_t)full * E * LN, acc + (size_t)full * nq * K * 2 * LN);
+}
+void launch_stage_a_batch(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const StageAQueries &qs, u32 nq, const u64 *db,
+                          u64 *acc, hipStream_t st, bool small_moduli, u32 bstride, u32 h0, u32 hn)
+{
+    if (!bstride) bstride = b;
+    if (!hn) hn = K - h0;
+    u32 q0 = 0;
+    while (small_moduli && nq - q0 >= 2) {
+        // groups of four, three or two queries (five: 3 + 2; six: 3 + 3; seven: 4 + 3)
+        const u32 left = nq - q0, g = left == 5 || left == 6 ? 3 : std::min(left, 4u);
+        StageAQueries sub;
+        for (u32 q = 0; q < g; q++) sub.idx[q] = qs.idx[q0 + q], sub.minus[q] = qs.minus[q0 + q];
+        if (g == 2) launch_stage_a_batch_q<2>(dc, N, L, K, b, E, sub, db, acc, st, bstride, h0, hn, nq, q0);
+        else if (g == 3) launch_stage_a_batch_q<3>(dc, N, L, K, b, E, sub, db, acc, st, bstride, h0, hn, nq, q0);
+        else launch_stage_a_batch_q<4>(dc, N, L, K, b, E, sub, db, acc, st, bstride, h0, hn, nq, q0);
+        q0 += g;
+    }
+    for (; q0 < nq; q0++)
+        launch_stage_a(dc, N, L, K, b, E, qs.idx[q0], qs.minus[q0], db, acc, st, small_moduli, bstride, h0, hn, nq, q0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1036,7 +1209,7 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restr
                                                         size_t stride01, const u64 *__restrict__ dig,
                                                         const u64 *__restrict__ key0, const u64 *__restrict__ mask,
                                                         u64 *__restrict__ out, const u32 *__restrict__ out_map,
-                                                        size_t key_stride, u32 key_group, u32 T)
+                                                        size_t key_stride, u32 key_group, u32 T, u32 mask_div)
 {
     constexpr bool TILE = KP > 0;
     constexpr u32 TT = TILE ? TPB / (KP ? KP : 1) : 1;  // threads of the transform per tile
@@ -1055,7 +1228,7 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restr
     const Mod m = dc->mod[j];
     const size_t LN = (size_t)L * N;
     u64x2 mk;
-    if (mask) mk = *reinterpret_cast<const u64x2 *>(mask + (size_t)bin * LN + (size_t)j * N + n);
+    if (mask) mk = *reinterpret_cast<const u64x2 *>(mask + (size_t)(bin / mask_div) * LN + (size_t)j * N + n);
     const u32 po = TILE ? 0 : (out_map ? out_map[n] : n);
     u64x2 res[2];
     if (MAD) {
@@ -1134,17 +1307,18 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restr
 }
 void launch_relin_mac(const DevConsts *dc, u32 N, u32 L, const u64 *d01, size_t stride01, const u64 *dig, const u64 *key,
                       const u64 *mask, u64 *out, u32 nb, hipStream_t st, const u32 *out_map, size_t key_stride, u32 key_group,
-                      u32 sigma_T, u32 sigma_kp)
+                      u32 sigma_T, u32 sigma_kp, u32 mask_div)
 {
     dim3 grid((N / 2 + TPB - 1) / TPB, L, nb);
     if (!key_group) key_group = 1;
+    if (!mask_div) mask_div = 1;
     // sigma_T: out_map is the lane order of a register-blocked transform with sigma_T threads per slice, sigma_kp pairs per thread
     const bool tile = out_map && (sigma_kp == 16 || sigma_kp == 8) && sigma_T >= TPB / sigma_kp && sigma_T % (TPB / sigma_kp) == 0 &&
                       (N / 2) % TPB == 0;
     const int kp = tile ? (int)sigma_kp : 0;
 #define RM(M_, K_)                                                                                                              \
     hipLaunchKernelGGL((relin_mac_kernel<M_, K_>), grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map, \
-                       key_stride, key_group, sigma_T)
+                       key_stride, key_group, sigma_T, mask_div)
     if (g_small_moduli) {
         if (kp == 16) RM(true, 16); else if (kp == 8) RM(true, 8); else RM(true, 0);
     } else {
@@ -1172,19 +1346,19 @@ void launch_ct_add(const DevConsts *dc, u32 N, u32 L, const u64 *x, const u64 *y
 }
 __global__ void __launch_bounds__(TPB) ct_mul_plain_kernel(const DevConsts *dc, u32 N, u32 L, const u64 *__restrict__ x,
                                                            const u64 *__restrict__ pt, size_t pt_stride,
-                                                           u64 *__restrict__ out)
+                                                           u64 *__restrict__ out, u32 pt_div)
 {
     const u32 n = blockIdx.x * TPB + threadIdx.x;
     if (n >= N) return;
     const u32 l = blockIdx.y % L;
     const size_t o = ((size_t)blockIdx.z * 2 * L + blockIdx.y) * N + n;
-    out[o] = mulmod(x[o], pt[(size_t)blockIdx.z * pt_stride + (size_t)l * N + n], dc->mod[l]);
+    out[o] = mulmod(x[o], pt[(size_t)(blockIdx.z / pt_div) * pt_stride + (size_t)l * N + n], dc->mod[l]);
 }
 void launch_ct_mul_plain(const DevConsts *dc, u32 N, u32 L, const u64 *x, const u64 *pt, size_t pt_stride, u64 *out,
-                         u32 nct, hipStream_t st)
+                         u32 nct, hipStream_t st, u32 pt_div)
 {
     dim3 grid((N + TPB - 1) / TPB, 2 * L, nct);
-    hipLaunchKernelGGL(ct_mul_plain_kernel, grid, dim3(TPB), 0, st, dc, N, L, x, pt, pt_stride, out);
+    hipLaunchKernelGGL(ct_mul_plain_kernel, grid, dim3(TPB), 0, st, dc, N, L, x, pt, pt_stride, out, pt_div ? pt_div : 1);
 }
 
 // ---------------------------------------------------------------------------------------------

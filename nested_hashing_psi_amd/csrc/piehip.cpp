@@ -36,6 +36,7 @@ static int fail(int code, const std::string &msg)
 struct piehip_ctx;
 static void join_pending(piehip_ctx *h);
 static void mark_dirty(piehip_ctx *h);
+static void free_workspace(piehip_ctx *h);
 // every entry point except piehip_run first orders the handle's stream behind the bin-layer queues of earlier runs
 #define NEED_RO(h)                                              \
     do {                                                        \
@@ -126,6 +127,12 @@ struct piehip_ctx {
     u64 *d_db = nullptr, *d_masks = nullptr;
     u64 *d_idx_own = nullptr, *d_minus_own = nullptr;
     const u64 *d_idx = nullptr, *d_minus = nullptr;
+    // query batch (piehip_set_query_batch): run() evaluates nq queries against the database at once; query 0 is d_idx / d_minus
+    // above, queries 1 .. nq - 1 are bq_*[q].  Workspace and results hold nq rows per bin layer: [b][nq][..].
+    u32 nq = 1;
+    u32 mask_div = 1;  // set while run() enqueues a batch: ciphertext row r of the product chain takes mask r / mask_div
+    const u64 *bq_idx[STAGE_A_MAX_QUERIES] = {}, *bq_minus[STAGE_A_MAX_QUERIES] = {};
+    u64 *bq_idx_own[STAGE_A_MAX_QUERIES] = {}, *bq_minus_own[STAGE_A_MAX_QUERIES] = {};
     // run() workspace
     u64 *d_acc = nullptr;   // [b][K][2][L][N]
     u64 *d_prod = nullptr;  // [b][2][L][N]  (K > 2 only)
@@ -317,7 +324,7 @@ static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, c
         ProfScope ps(h, PIEHIP_K_RELIN, W * (nb * ((double)L * L + 2 * L + 2 * L + (mask ? L : 0)) + 2.0 * L * L));
         launch_relin_mac(h->d_dc, N, L, w.d01, 2 * LN, w.dig, key, mask, out, nb, h->stream,
                          (sigma && h->sigma_on) ? h->d_sigma_inv : nullptr, key_stride, key_group,
-                         (sigma && h->sigma_on) ? h->sigma_T : 0, h->sigma_kp);
+                         (sigma && h->sigma_on) ? h->sigma_T : 0, h->sigma_kp, mask ? h->mask_div : 1);
     }
 }
 
@@ -567,10 +574,11 @@ int piehip_destroy(piehip_handle h)
     dev_free(&h->d_masks);
     dev_free(&h->d_idx_own);
     dev_free(&h->d_minus_own);
-    dev_free(&h->d_acc);
-    dev_free(&h->d_prod);
-    dev_free(&h->d_out);
-    ws_free(h->ws);
+    for (u32 q = 0; q < STAGE_A_MAX_QUERIES; q++) {
+        dev_free(&h->bq_idx_own[q]);
+        dev_free(&h->bq_minus_own[q]);
+    }
+    free_workspace(h);
     if (h->d_dc) (void)hipFree(h->d_dc);
     if (h->d_tables) (void)hipFree(h->d_tables);
     if (h->d_twp) (void)hipFree(h->d_twp);
@@ -682,6 +690,24 @@ static int make_masks_sigma(piehip_ctx *h)
     return PIEHIP_OK;
 }
 
+// run() workspace and result rows for b bin layers x nq queries of K inner hash functions
+static void free_workspace(piehip_ctx *h)
+{
+    dev_free(&h->d_acc);
+    dev_free(&h->d_prod);
+    dev_free(&h->d_out);
+    ws_free(h->ws);
+}
+static int alloc_workspace(piehip_ctx *h, u32 K, u32 b)
+{
+    const size_t LN = h->LN(), rows = (size_t)b * h->nq;
+    int rc;
+    if ((rc = dev_alloc(&h->d_acc, rows * K * 2 * LN))) return rc;
+    if ((rc = dev_alloc(&h->d_out, rows * 2 * LN))) return rc;
+    if (K > 2 && (rc = dev_alloc(&h->d_prod, rows * 2 * LN))) return rc;
+    return ws_alloc(h, h->ws, (u32)rows);
+}
+
 static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E, bool with_db = true)
 {
     drop_graph(h);  // the captured launches hold the addresses and shapes of the buffers below
@@ -696,27 +722,22 @@ static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E, bool with_db = 
     if (with_db && h->db_borrowers)
         return fail(PIEHIP_ESTATE, "a database cannot be loaded while other handles are attached to this one (destroy or re-home them first)");
     const size_t LN = h->LN();
-    if (with_db && h->K == K && h->b == b && h->E == E && h->d_db && h->d_masks && h->d_acc && h->d_out && h->ws.nb == b) {
+    if (with_db && h->K == K && h->b == b && h->E == E && h->d_db && h->d_masks && h->d_acc && h->d_out && h->ws.nb == b * h->nq) {
         // same shape as the database being replaced (or reserved): keep the 0.5 GiB of buffers (hipFree + hipMalloc cost
         // ~10 ms); the inputs of the previous database are stale
         h->d_idx = nullptr;
+        for (u32 q = 1; q < STAGE_A_MAX_QUERIES; q++) h->bq_idx[q] = nullptr;
         return PIEHIP_OK;
     }
     dev_free(&h->d_db);
     dev_free(&h->d_masks);
     dev_free(&h->d_masks_sigma);
-    dev_free(&h->d_acc);
-    dev_free(&h->d_prod);
-    dev_free(&h->d_out);
-    ws_free(h->ws);
+    free_workspace(h);
     h->K = h->b = h->E = 0;
     int rc;
     if (with_db && (rc = dev_alloc(&h->d_db, (size_t)K * b * E * LN))) return rc;
     if (with_db && (rc = dev_alloc(&h->d_masks, (size_t)b * LN))) return rc;
-    if ((rc = dev_alloc(&h->d_acc, (size_t)b * K * 2 * LN))) return rc;
-    if ((rc = dev_alloc(&h->d_out, (size_t)b * 2 * LN))) return rc;
-    if (K > 2 && (rc = dev_alloc(&h->d_prod, (size_t)b * 2 * LN))) return rc;
-    if ((rc = ws_alloc(h, h->ws, b))) return rc;
+    if ((rc = alloc_workspace(h, K, b))) return rc;
     h->K = K;
     h->b = b;
     h->E = E;
@@ -724,6 +745,10 @@ static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E, bool with_db = 
     h->stage_open = false;
     dev_free(&h->d_idx_own);
     h->d_idx = nullptr;
+    for (u32 q = 1; q < STAGE_A_MAX_QUERIES; q++) {
+        dev_free(&h->bq_idx_own[q]);
+        h->bq_idx[q] = nullptr;
+    }
     return PIEHIP_OK;
 }
 
@@ -1108,6 +1133,88 @@ int piehip_set_minus_device(piehip_handle h, const void *d_minus)
     return PIEHIP_OK;
 }
 
+// ---- query batches --------------------------------------------------------------------------------------------------------
+// run() over nq queries at once (each with its own index matrix and minus element) against the handle's database.  Stage A
+// reads every database plaintext once for the batch instead of once per query, and every later launch works on nq times as
+// many ciphertexts.  Rows of the workspace and of the results: [bin layer][query].
+int piehip_set_query_batch(piehip_handle h, uint32_t nq)
+{
+    NEED(h);
+    if (nq < 1 || nq > STAGE_A_MAX_QUERIES) return fail(PIEHIP_EINVAL, "set_query_batch: between 1 and 8 queries per run()");
+    if (nq == h->nq) return PIEHIP_OK;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    drop_graph(h);
+    h->stage_open = false;
+    h->nq = nq;
+    if (!h->K) return PIEHIP_OK;  // the database's arrival sizes the workspace
+    free_workspace(h);
+    return alloc_workspace(h, h->K, h->b);
+}
+int piehip_get_query_batch(piehip_handle h, uint32_t *nq)
+{
+    NEED_RO(h);
+    if (!nq) return fail(PIEHIP_EINVAL, "null out");
+    *nq = h->nq;
+    return PIEHIP_OK;
+}
+static int batch_query_check(piehip_ctx *h, u32 q)
+{
+    if (q >= h->nq) return fail(PIEHIP_EINVAL, "query index outside the batch (piehip_set_query_batch)");
+    return PIEHIP_OK;
+}
+int piehip_set_index_device_q(piehip_handle h, uint32_t q, const void *d_idx)
+{
+    if (q == 0) return piehip_set_index_device(h, d_idx);
+    NEED(h);
+    if (!d_idx) return fail(PIEHIP_EINVAL, "null index matrix");
+    int rc = batch_query_check(h, q);
+    if (rc) return rc;
+    h->bq_idx[q] = (const u64 *)d_idx;
+    return PIEHIP_OK;
+}
+int piehip_set_minus_device_q(piehip_handle h, uint32_t q, const void *d_minus)
+{
+    if (q == 0) return piehip_set_minus_device(h, d_minus);
+    NEED(h);
+    if (!d_minus) return fail(PIEHIP_EINVAL, "null minus element");
+    int rc = batch_query_check(h, q);
+    if (rc) return rc;
+    h->bq_minus[q] = (const u64 *)d_minus;
+    return PIEHIP_OK;
+}
+int piehip_set_index_q(piehip_handle h, uint32_t q, const uint64_t *idx)
+{
+    if (q == 0) return piehip_set_index(h, idx);
+    NEED(h);
+    if (!idx) return fail(PIEHIP_EINVAL, "null index matrix");
+    if (!h->K) return fail(PIEHIP_ESTATE, "load the database before the index matrix");
+    int rc = batch_query_check(h, q);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t words = (size_t)h->K * h->E * 2 * h->LN();
+    if (!h->bq_idx_own[q] && (rc = dev_alloc(&h->bq_idx_own[q], words))) return rc;
+    HIPCHK(hipMemcpyAsync(h->bq_idx_own[q], idx, words * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->bq_idx[q] = h->bq_idx_own[q];
+    return PIEHIP_OK;
+}
+int piehip_set_minus_q(piehip_handle h, uint32_t q, const uint64_t *minus)
+{
+    if (q == 0) return piehip_set_minus(h, minus);
+    NEED(h);
+    if (!minus) return fail(PIEHIP_EINVAL, "null minus element");
+    int rc = batch_query_check(h, q);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t words = 2 * h->LN();
+    if (!h->bq_minus_own[q] && (rc = dev_alloc(&h->bq_minus_own[q], words))) return rc;
+    HIPCHK(hipMemcpyAsync(h->bq_minus_own[q], minus, words * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->bq_minus[q] = h->bq_minus_own[q];
+    return PIEHIP_OK;
+}
+
 // Queues of a run().  The default is two when the handle evaluates enough bin layers to fill the chip twice over; below that
 // every launch is bound by its own latency, a second queue only interleaves two latency-bound chains on the same CUs, and one
 // queue is faster (measured at the C3 ring: 2 layers 115 vs 146 us, 5 layers of the E = 40 row 217 vs 239 us, 7 layers even).
@@ -1147,23 +1254,37 @@ static u32 run_group_size(u32 b, u32 ng, u32 g)
 // Bin layers [b0, b0 + nb) of run() on the handle's current stream: stage A, then the product chain.
 static void enqueue_run_bins(piehip_ctx *h, u32 b0, u32 nb, u64 *results)
 {
-    const u32 N = h->hp.N, L = h->hp.L, M = h->hp.M, K = h->K, b = h->b, E = h->E;
+    const u32 N = h->hp.N, L = h->hp.L, M = h->hp.M, K = h->K, b = h->b, E = h->E, nq = h->nq;
     const size_t LN = h->LN();
     const double W = 8.0 * N;
+    // rows of the workspace: (bin layer, query) pairs, nq per layer; the product chain sees nb * nq ciphertexts
+    const size_t r0 = (size_t)b0 * nq;
+    const u32 layers = nb;
+    nb *= nq;
     MulWs w = h->ws;  // view of the workspace rows of these bin layers
     w.nb = nb;
-    w.eqp += (size_t)b0 * 4 * M * N;
-    w.dqp += (size_t)b0 * 3 * M * N;
-    w.d01 += (size_t)b0 * 2 * LN;
-    w.d2c += (size_t)b0 * LN;
-    w.dig += (size_t)b0 * L * LN;
-    u64 *acc = h->d_acc + (size_t)b0 * K * 2 * LN;
-    u64 *prod = h->d_prod ? h->d_prod + (size_t)b0 * 2 * LN : nullptr;
-    u64 *out = results + (size_t)b0 * 2 * LN;
+    w.eqp += r0 * 4 * M * N;
+    w.dqp += r0 * 3 * M * N;
+    w.d01 += r0 * 2 * LN;
+    w.d2c += r0 * LN;
+    w.dig += r0 * L * LN;
+    u64 *acc = h->d_acc + r0 * K * 2 * LN;
+    u64 *prod = h->d_prod ? h->d_prod + r0 * 2 * LN : nullptr;
+    u64 *out = results + r0 * 2 * LN;
     const u64 *masks = (h->sigma_on ? h->d_masks_sigma : h->d_masks) + (size_t)b0 * LN;
+    struct MaskDiv {
+        piehip_ctx *h;
+        ~MaskDiv() { h->mask_div = 1; }
+    } mask_div_scope{h};
+    h->mask_div = nq;
     {   // stage A: all inner products of these bin layers in one launch (BatchedFHEHIPPIE.cpp:101-116)
-        ProfScope ps(h, PIEHIP_K_STAGE_A, W * ((double)nb * K * E * L + (double)K * E * 2 * L + 2.0 * L + (double)nb * K * 2 * L));
-        if (h->row_events) {
+        ProfScope ps(h, PIEHIP_K_STAGE_A, W * ((double)layers * K * E * L + nq * ((double)K * E * 2 * L + 2.0 * L + (double)layers * K * 2 * L)));
+        if (nq > 1) {
+            StageAQueries qs;
+            qs.idx[0] = h->d_idx, qs.minus[0] = h->d_minus;
+            for (u32 q = 1; q < nq; q++) qs.idx[q] = h->bq_idx[q], qs.minus[q] = h->bq_minus[q];
+            launch_stage_a_batch(h->d_dc, N, L, K, layers, E, qs, nq, h->d_db + (size_t)b0 * E * LN, acc, h->stream, h->small_moduli, b);
+        } else if (h->row_events) {
             // the index matrix is still arriving over PCIe: one launch per inner hash function, each behind its own row
             for (u32 hf = 0; hf < K; hf++) {
                 (void)hipStreamWaitEvent(h->stream, h->row_events[hf], 0);
@@ -1178,7 +1299,7 @@ static void enqueue_run_bins(piehip_ctx *h, u32 b0, u32 nb, u64 *results)
         // stage A and the mask multiply (:126) -- no ciphertext product, no transform, no key
         if (h->wait_before_results) (void)hipStreamWaitEvent(h->stream, h->wait_before_results, 0);
         ProfScope ps(h, PIEHIP_K_MASK, W * nb * 5.0 * L);
-        launch_ct_mul_plain(h->d_dc, N, L, acc, h->d_masks + (size_t)b0 * LN, LN, out, nb, h->stream);
+        launch_ct_mul_plain(h->d_dc, N, L, acc, h->d_masks + (size_t)b0 * LN, LN, out, nb, h->stream, nq);
         return;
     }
     // every accumulator enters a ct x ct product exactly once: switch them all to COEFFICIENT format
@@ -1213,6 +1334,9 @@ int piehip_run_into(piehip_handle h, void *d_results)
     if (!h->K || !h->d_db) return fail(PIEHIP_ESTATE, "run: database not loaded");
     if (!h->d_evk && h->K > 1) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
     if (!h->d_idx || !h->d_minus) return fail(PIEHIP_ESTATE, "run: setIndex / setMinusCompareElement not called");
+    for (u32 q = 1; q < h->nq; q++)
+        if (!h->bq_idx[q] || !h->bq_minus[q]) return fail(PIEHIP_ESTATE, "run: a query of the batch has no index matrix or minus element");
+    if (h->nq > 1 && h->row_events) return fail(PIEHIP_ESTATE, "run: staged uploads take one query per run()");
     HIPCHK(hipSetDevice(h->device));
     const u32 b = h->b;
     h->recs.clear();
@@ -1230,7 +1354,7 @@ int piehip_run_into(piehip_handle h, void *d_results)
         const int qrc = ensure_run_queues(h, ng);
         if (qrc) return qrc;
     }
-    if (h->use_graph && !h->profiling && !h->row_events) {
+    if (h->use_graph && !h->profiling && !h->row_events && h->nq == 1) {
         // One graph launch instead of ~13 kernel launches and 2 event operations per queue group: the same two chains, forked
         // from and joined back to the handle's stream inside the graph (so consecutive runs do not overlap each other, which
         // the eager path's lazy join allows).
@@ -1320,6 +1444,7 @@ int piehip_run(piehip_handle h)
 
 static int host_path_setup(piehip_ctx *h)
 {
+    if (h->nq > 1) return fail(PIEHIP_ESTATE, "the host-buffer path takes one query per run() (piehip_set_query_batch(h, 1))");
     if (!h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     if (!h->ev_copy_gate) HIPCHK(hipEventCreateWithFlags(&h->ev_copy_gate, hipEventDisableTiming));
     if (!h->ev_minus_h2d) HIPCHK(hipEventCreateWithFlags(&h->ev_minus_h2d, hipEventDisableTiming));
@@ -1518,7 +1643,7 @@ int piehip_get_results(piehip_handle h, uint64_t *out)
     if (!out) return fail(PIEHIP_EINVAL, "null out");
     if (!h->d_out) return fail(PIEHIP_ESTATE, "no results");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemcpyAsync(out, h->d_out, sizeof(u64) * (size_t)h->b * 2 * h->LN(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(out, h->d_out, sizeof(u64) * (size_t)h->b * h->nq * 2 * h->LN(), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return PIEHIP_OK;
 }
@@ -1535,7 +1660,7 @@ int piehip_copy_results_device(piehip_handle h, void *d_dst)
     NEED(h);
     if (!d_dst) return fail(PIEHIP_EINVAL, "null destination");
     if (!h->d_out) return fail(PIEHIP_ESTATE, "no results");
-    HIPCHK(hipMemcpyAsync(d_dst, h->d_out, sizeof(u64) * (size_t)h->b * 2 * h->LN(), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_dst, h->d_out, sizeof(u64) * (size_t)h->b * h->nq * 2 * h->LN(), hipMemcpyDeviceToDevice, h->stream));
     return PIEHIP_OK;
 }
 

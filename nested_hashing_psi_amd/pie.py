@@ -295,26 +295,39 @@ class BatchedFHEHIPPIE:
         _check(lib().piehip_get_hash_table(self.cc._h, out.ctypes.data_as(u64p)))
         return out
 
-    def setIndex(self, indexMatrix):
+    def setQueryBatch(self, nq):
+        """run() evaluates nq queries at once against the database (piehip_set_query_batch): setIndex / setMinusCompareElement take
+        query=q, getResultList returns [nq][b] ciphertexts.  The reference operator has one query per run()."""
+        _check(lib().piehip_set_query_batch(self.cc._h, int(nq)))
+        self._results = None
+
+    @property
+    def nq(self):
+        """queries per run() of the handle (piehip_get_query_batch)"""
+        n = C.c_uint32()
+        _check(lib().piehip_get_query_batch(self.cc._h, C.byref(n)))
+        return n.value
+
+    def setIndex(self, indexMatrix, query=0):
         a, ap = _u64(indexMatrix)
         if a.shape != (self.K, self.E, 2, self.cc.L, self.cc.N):
             raise ValueError("index matrix must be [K][E] ciphertexts")
-        _check(lib().piehip_set_index(self.cc._h, ap))
+        _check(lib().piehip_set_index_q(self.cc._h, query, ap))
 
-    def setMinusCompareElement(self, minusCompareElement):
+    def setMinusCompareElement(self, minusCompareElement, query=0):
         a, ap = _u64(minusCompareElement)
         if a.shape != (2, self.cc.L, self.cc.N):
             raise ValueError("minus element must be one ciphertext")
-        _check(lib().piehip_set_minus(self.cc._h, ap))
+        _check(lib().piehip_set_minus_q(self.cc._h, query, ap))
 
-    def setIndexDevice(self, ptr):
-        _check(lib().piehip_set_index_device(self.cc._h, ptr))
+    def setIndexDevice(self, ptr, query=0):
+        _check(lib().piehip_set_index_device_q(self.cc._h, query, ptr))
 
-    def setMinusCompareElementDevice(self, ptr):
-        _check(lib().piehip_set_minus_device(self.cc._h, ptr))
+    def setMinusCompareElementDevice(self, ptr, query=0):
+        _check(lib().piehip_set_minus_device_q(self.cc._h, query, ptr))
 
     def run(self, sync=True, into=None):
-        """into: device address of a caller-owned result buffer [b][2][L][N] (piehip_run_into)"""
+        """into: device address of a caller-owned result buffer [b][2][L][N] (piehip_run_into; [b][nq][2][L][N] for a query batch)"""
         if into is None:
             _check(lib().piehip_run(self.cc._h))
         else:
@@ -390,12 +403,17 @@ class BatchedFHEHIPPIE:
         """the b result ciphertexts.  As in the reference (BatchedFHEHIPPIE.hpp:35-38 returns a reference to the member
         vector) the array belongs to the operator and is overwritten by the next call; copy it to keep it.  (A fresh
         14 MiB numpy array per query costs ~25 ms of first-touch page faults under the device-to-host copy.)"""
+        nq = self.nq
+        want = (self.b, 2, self.cc.L, self.cc.N) if nq == 1 else (self.b, nq, 2, self.cc.L, self.cc.N)
+        if getattr(self, "_results", None) is not None and self._results.shape != want:
+            self._results = None
         if getattr(self, "_results", None) is None:
-            self._results = np.empty((self.b, 2, self.cc.L, self.cc.N), dtype=np.uint64)
+            self._results = np.empty((self.b, 2, self.cc.L, self.cc.N) if nq == 1 else (self.b, nq, 2, self.cc.L, self.cc.N), dtype=np.uint64)
             self._results.fill(0)
         out = self._results
         _check(lib().piehip_get_results(self.cc._h, out.ctypes.data_as(u64p)))
-        return out
+        # a query batch: the library's rows are [bin layer][query]; hand back [query][bin layer] (a view)
+        return out if nq == 1 else out.transpose(1, 0, 2, 3, 4)
 
     def copyResultsToDevice(self, ptr):
         _check(lib().piehip_copy_results_device(self.cc._h, ptr))

@@ -689,6 +689,77 @@ def test_caller_supplied_moduli(ob, pie, N, L, t, below, what):
     cc.close()
 
 
+@pytest.mark.parametrize("N,L,t,K,E,b,nqs", [
+    (4096, 2, T16, 2, 4, 5, (2, 3, 4, 5, 8)),      # every group size of stage A's batch kernel: 2, 3, 4, 3 + 2, 4 + 4; b = 5 = 4 + 1 / 2 + 2 + 1
+    (16384, 4, T32, 2, 3, 14, (2, 3)),             # the headline ring, two queues (8 + 6 layers), folded transforms
+    (2048, 3, T32, 3, 17, 4, (2, 7)),              # K = 3 (two chained products), E > 15: carry sweeps and a mid-sum reduction
+    (4096, 2, T16, 1, 6, 3, (2, 4)),               # K = 1: stage A + mask multiply
+    (8192, 3, T32, 2, 4, 7, (6,)),                 # 3 + 3 queries, b = 7: 4 + 3 / 2 + 2 + 2 + 1 layers per thread
+])
+def test_query_batches(ob, pie, N, L, t, K, E, b, nqs):
+    """piehip_set_query_batch: run() over nq queries at once.  Every query's ciphertexts equal the oracle's for that query alone
+    (random limbs), whatever the batch size, the queue count and the order the inputs were set in; the host-buffer path is
+    refused in batch mode and works again after returning to one query per run()."""
+    import torch
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(N + 7 * K + b)
+    q = cc.q
+    db, masks, evk = rand_limbs(rng, q, (K, b, E), N), rand_limbs(rng, q, (b,), N), rand_limbs(rng, q, (L, 2), N)
+    if K > 1:
+        cc.load_relin_key(evk)
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    nmax = max(nqs)
+    queries = [(rand_limbs(rng, q, (K, E, 2), N), rand_limbs(rng, q, (2,), N)) for _ in range(nmax)]
+    want = [o.pie_run(idx, minus, db, masks, evk) for idx, minus in queries]
+    for nq in nqs:
+        op.setQueryBatch(nq)
+        with pytest.raises(ValueError):
+            op.setIndex(queries[0][0], query=nq)
+        order = list(rng.permutation(nq))
+        dev = []
+        for i in order:
+            idx, minus = queries[i]
+            if i % 2:   # odd queries: inputs already resident in HBM
+                di, dm = torch.from_numpy(idx.view(np.int64)).cuda(), torch.from_numpy(minus.view(np.int64)).cuda()
+                dev += [di, dm]
+                op.setIndexDevice(di.data_ptr(), query=int(i))
+                op.setMinusCompareElementDevice(dm.data_ptr(), query=int(i))
+            else:
+                op.setMinusCompareElement(minus, query=int(i))
+                op.setIndex(idx, query=int(i))
+        torch.cuda.synchronize()
+        for streams in (0, 1):
+            cc.set_run_streams(streams)
+            op.run()
+            op.run()    # back-to-back runs of the same batch
+            got = op.getResultList()
+            assert got.shape == (nq, b, 2, L, N)
+            for i in range(nq):
+                assert (got[i] == want[i]).all(), "query %d of a batch of %d" % (i, nq)
+        with pytest.raises(RuntimeError):
+            op.hostBuffers()
+    op.setQueryBatch(1)
+    idx, minus = queries[1]
+    assert (op.runHost(idx, minus) == want[1]).all()
+    op.setQueryBatch(2)
+    op.setIndex(queries[0][0])
+    op.setMinusCompareElement(queries[0][1])
+    op.setIndex(queries[1][0], query=1)
+    op.setMinusCompareElement(queries[1][1], query=1)
+    op.run()
+    got = op.getResultList()
+    assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+    op2 = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)   # same shape: the inputs of the old database are stale
+    op2.setIndex(queries[0][0])
+    op2.setMinusCompareElement(queries[0][1])
+    with pytest.raises(RuntimeError, match="query of the batch"):
+        op2.run()
+    with pytest.raises(ValueError):
+        op.setQueryBatch(9)
+    cc.close()
+
+
 @pytest.mark.parametrize("E,b", [(1, 1), (1, 3), (15, 2), (16, 3), (40, 5)])
 def test_run_shape_extremes(ob, pie, E, b):
     """one inner position, the last E of the carry-free accumulator (15), the first E of the 128-bit accumulator (16), a long
