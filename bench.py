@@ -312,7 +312,10 @@ def time_slots(ops, steps, warmup, sync, repeats=7, warm_seconds=0.1):
 
 
 PROJECTION_IN_FLIGHT = 3
-DEFAULT_BATCH = 1
+# The default timed region: three queries per run() on one handle (a query batch: piehip_set_query_batch).  Until round 3 the
+# default was three query slots in flight with one query each; the batch serves the same three clients 5-6 % faster (stage A
+# streams the database once for the three, the transform launches are three times the size).  Both are measured; see main().
+DEFAULT_BATCH = 3
 
 
 def projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, steps, warmup):
@@ -474,6 +477,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end PSI wall-clock leg")
     ap.add_argument("--no-projection", action="store_true", help="skip the projected strong-scaling legs")
     ap.add_argument("--no-ref-timer", action="store_true", help="skip the host-inputs (reference timer placement) leg")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="only the timed region and the per-kernel passes: no further legs (for profiler runs, whose per-kernel "
+                         "averages should see one launch shape per kernel)")
     ap.add_argument("--graph", action="store_true", help="run() as one captured hipGraph (piehip_set_graph)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="queries in flight: query slots (own stream + workspace, one shared database: piehip_attach_database) that "
@@ -499,6 +505,8 @@ def main():
     ap.add_argument("--query-source", default="hbm", choices=["hbm", "host"],
                     help="N > 1: rank 0's copy of the query is resident in HBM (as at N = 1) or in page-locked host memory")
     args = ap.parse_args()
+    if args.timed_only:
+        args.no_cpu_baseline = args.no_e2e = args.no_projection = args.no_ref_timer = True
 
     # stdout carries exactly one JSON line: libraries that print banners to fd 1 (RCCL's version block) go to stderr
     sys.stdout.flush()
@@ -557,31 +565,40 @@ def main():
     torch.cuda.synchronize(device)
     cc.load_relin_key(evk.cpu().numpy().view(np.uint64))
     op = synthetic_operator(pie, cc, cfg, b_local, rng, (idx, minus)) if b_local > 0 else None
-    # Queries in flight.  One query's ct x pt stage is HBM-bound while another's transforms are ALU-bound, and a small share
-    # of bin layers leaves most of the chip idle: further query slots (a context with its own stream and run() workspace,
-    # reading slot 0's key and database by reference) take the steps round-robin.  Every step is still one full run() over
-    # its own inputs into its own result buffer.  With slots, one queue per run() is the faster setting (measured).
-    # three: the HIP runtime multiplexes streams onto four hardware queues, and streams that share one serialise (measured:
-    # 2 / 3 / 4 / 6 slots -> 259 / 249 / 264 / 252 us per C3 query, 76 / 59 / 74 / 63 us per query of a 2-layer share)
-    in_flight = args.in_flight or 3
+    # Several queries at once, two ways.
+    # Queries in flight (--in-flight): further query slots (a context with its own stream and run() workspace, reading slot 0's
+    # key and database by reference) take the steps round-robin; one query's ct x pt stage is HBM-bound while another's
+    # transforms are ALU-bound, and a small share of bin layers leaves most of the chip idle.  With slots, one queue per run()
+    # is the faster setting; three slots, because the HIP runtime multiplexes streams onto four hardware queues and streams that
+    # share one serialise (profiles/r03/queries_in_flight.txt).
+    # Queries per run() (--batch).  A server with several clients waiting evaluates their queries together: stage A streams the packed
+    # database (3/4 of its traffic) once for the batch, and every later launch carries `batch` times the ciphertexts.
+    # Defaults: a batch of three on one handle (one GPU); three slots with one query each where batches do not apply (N > 1:
+    # the gather's buffers are per query; --graph; a rank's share of a few bin layers).
+    batching = not (use_dist or args.graph or op is None or args.bins_per_rank)
+    if args.batch:
+        batch = args.batch if batching else 1
+        in_flight = args.in_flight or 1
+    elif args.in_flight or not batching:
+        batch, in_flight = 1, args.in_flight or 3
+    else:
+        batch, in_flight = DEFAULT_BATCH, 1
     if args.graph:
         in_flight = 1
     run_streams = args.streams or (1 if in_flight > 1 else 0)
     cc.set_run_streams(run_streams)
     cc.set_graph(args.graph)
     slots = [(cc, op, stream, idx, minus)]
-    if in_flight > 1 and op is not None:
-        slots += make_query_slots(torch, pie, cc, op, (N, L, t, K, E), in_flight, device, local_rank, gen, run_streams)
-    elif in_flight > 1:   # a rank without bin layers still takes part in every slot's collective
-        slots += [(None, None, torch.cuda.Stream(device), None, None) for _ in range(1, in_flight)]
-    # Queries per run().  A server with several clients waiting evaluates their queries together: stage A streams the packed
-    # database (3/4 of its traffic) once for the batch, and every later launch carries `batch` times the ciphertexts.
-    batch = max(1, args.batch or DEFAULT_BATCH)
-    if use_dist or args.graph or op is None:
-        batch = 1
+    # (one GPU: two further slots exist in any case -- the legs after the timed region use them -- but only the first
+    # `in_flight` take steps)
+    n_slots = max(in_flight, 3) if (batching and not args.no_ref_timer) or (batching and batch > 1) else in_flight
+    if n_slots > 1 and op is not None:
+        slots += make_query_slots(torch, pie, cc, op, (N, L, t, K, E), n_slots, device, local_rank, gen, args.streams or 1)
+    elif n_slots > 1:   # a rank without bin layers still takes part in every slot's collective
+        slots += [(None, None, torch.cuda.Stream(device), None, None) for _ in range(1, n_slots)]
     extra_inputs = []
     if batch > 1:
-        for c_, o_, st_, i_, m_ in slots:
+        for c_, o_, st_, i_, m_ in slots[:in_flight]:
             o_.setQueryBatch(batch)
             for q_ in range(1, batch):
                 iq = uniform_limbs(torch, (K, E, 2), cc.q, N, device, gen)
@@ -669,7 +686,7 @@ def main():
     nstep = [0]
 
     def step():
-        i_ = nstep[0] % len(slots)
+        i_ = nstep[0] % in_flight
         nstep[0] += 1
         if rgs:
             rgs[i_].step()      # query distribution, run() into a gather buffer, gather of the results, double-buffered
@@ -696,9 +713,9 @@ def main():
     t_w = time.perf_counter()
     done_w = 0
     while True:
-        for _ in range(max(args.warmup, len(slots))):
+        for _ in range(max(args.warmup, in_flight)):
             step()
-        done_w += max(args.warmup, len(slots))
+        done_w += max(args.warmup, in_flight)
         finish()
         if agree(time.perf_counter() - t_w, dist.ReduceOp.MIN if dist else None) >= args.warm_seconds:
             break
@@ -753,10 +770,11 @@ def main():
                         "avg_launch_us": 1e3 * ntt_ms / ntt_launch, "alg_bytes_per_launch": ntt_bytes / ntt_launch,
                         "launches_per_step": ntt_launch,
                         "measured": "HIP events around every launch, median of %d serial passes of run() after a warm-up (one stream; the "
-                                    "timed region uses %s)" % (len(passes), "%d queue(s) per run(), %d queries in flight" % (run_streams or 2, in_flight))}
+                                    "timed region uses %s)" % (len(passes), "%d queue(s) per run(), %d quer%s per run(), %d run() in flight"
+                                                              % (run_streams or 2, batch, "y" if batch == 1 else "ies", in_flight))}
 
     if batch > 1:   # the legs below take one query per run()
-        for c_, o_, st_, i_, m_ in slots:
+        for c_, o_, st_, i_, m_ in slots[:in_flight]:
             o_.setQueryBatch(1)
     if rank == 0:
         value = batch * b_total / (ms_per_step * 1e-3)
@@ -792,14 +810,25 @@ def main():
                              "note": "bytes of the reference's unfused schedule / measured time / 8 TB/s; not measured HBM traffic"},
             "roofline": roofline, "kernels": kernels,
         }
-        if world == 1 and op is not None and in_flight > 1 and not args.bins_per_rank:
-            # the same steps with one query at a time (one slot, the library's default of two queues per run())
+        if world == 1 and op is not None and (in_flight > 1 or batch > 1) and not args.bins_per_rank and not args.timed_only:
+            # the same steps with one query at a time (one slot, one query per run(), the library's default of two queues)
             cc.set_run_streams(args.streams)
             one_ms = time_runs(op, args.steps, args.warmup, lambda: torch.cuda.synchronize(device), repeats=args.repeats, warm_seconds=0.15)
-            cc.set_run_streams(run_streams)
             line["one_query_at_a_time"] = {"ms_per_step": one_ms, "value": b_total / (one_ms * 1e-3), "run_streams": args.streams or 2}
+            if len(slots) >= 3 and not (in_flight == 3 and batch == 1):
+                # ... and with three query slots in flight, one query per run() each, one queue per run(): the default timed
+                # region of rounds 2 and 3 before query batches
+                cc.set_run_streams(1)
+                tri_ms = time_slots([s_[1] for s_ in slots[:3]], args.steps, args.warmup, lambda: torch.cuda.synchronize(device),
+                                    repeats=args.repeats, warm_seconds=0.15)
+                line["three_query_slots_in_flight"] = {"ms_per_step": tri_ms, "value": b_total / (tri_ms * 1e-3), "run_streams": 1,
+                                                       "queries_per_step": 1}
+            cc.set_run_streams(run_streams)
         if world == 1 and op is not None and not args.no_ref_timer:
+            if len(slots) > 1:
+                cc.set_run_streams(args.streams or 1)   # the pipelined leg keeps every slot on one queue per run()
             rt = reference_timer(torch, op, idx, minus, b_local, 15, device, [(s_[1], s_[3], s_[4]) for s_ in slots[1:]], run_streams)
+            cc.set_run_streams(run_streams)
             line["ref_timer"] = rt
             # reference timer placement, query in host memory, result list back in host memory when the timer stops: one query
             # (latency), and a stream of queries over the query slots (throughput)

@@ -222,6 +222,8 @@ public:
         minusStaged = true;
     }
 
+    friend class BatchedFHEHIPPIEQueryBatch;
+
 protected:
     size_t ctWords() const { return 2 * (size_t)cc.towers() * cc.ringDimension(); }
     void initStaging()
@@ -237,6 +239,65 @@ protected:
     std::vector<uint32_t> rowCount;
     uint32_t rowsStaged = 0, arrived = 0;
     bool minusStaged = false, rerun = false, listStale = false;
+};
+
+// Several queries per run() (piehip_set_query_batch): a server with clients waiting evaluates their queries together -- stage A
+// then streams the packed database once for the batch, and every later launch carries nq times the ciphertexts.  The reference
+// operator has one query per run() (BatchedFHEHIPPIE.hpp:40-48); this class keeps its call order per query:
+// setMinusCompareElement(q, ..), setIndex(q, ..) for every q < nq, run(), getResultList(q).  Every query's result list is
+// bit-identical to what BatchedFHEHIPPIE::run() gives for that query alone.
+// `cryptoContext` is a context of its own (same parameters as `database`'s, its own stream and workspace) attached to
+// `database`'s key and packed table; `database` must outlive this object.
+class BatchedFHEHIPPIEQueryBatch {
+public:
+    BatchedFHEHIPPIEQueryBatch(PieContext &cryptoContext, const BatchedFHEHIPPIE &database, uint32_t queriesPerRun)
+        : cc(cryptoContext), K(database.K), b(database.b), E(database.E), nq(queriesPerRun)
+    {
+        PieContext::check(piehip_attach_database(cc.handle(), database.cc.handle()));
+        PieContext::check(piehip_set_query_batch(cc.handle(), nq));
+        results.resize((size_t)b * nq * ctWords());
+        lists.assign(nq, std::vector<LimbCt>(b));
+        row.resize((size_t)K * E * ctWords());
+    }
+    uint32_t queriesPerRun() const { return nq; }
+
+    void setIndex(uint32_t q, std::vector<std::vector<LimbCt>> &&indexMatrix)  // [K][E] ciphertexts of query q
+    {
+        const size_t ct = ctWords();
+        if (indexMatrix.size() != K) throw std::invalid_argument("index matrix must have one row per inner hash function");
+        for (uint32_t h = 0; h < K; h++) {
+            if (indexMatrix[h].size() != E) throw std::invalid_argument("index matrix row length must be eachCuckooTableSize");
+            for (uint32_t j = 0; j < E; j++) {
+                if (indexMatrix[h][j].limbs.size() != ct) throw std::invalid_argument("ciphertext does not match the context");
+                std::memcpy(&row[((size_t)h * E + j) * ct], indexMatrix[h][j].limbs.data(), ct * sizeof(uint64_t));
+            }
+        }
+        PieContext::check(piehip_set_index_q(cc.handle(), q, row.data()));
+    }
+    void setMinusCompareElement(uint32_t q, const LimbCt &minusCompareElement)
+    {
+        if (minusCompareElement.limbs.size() != ctWords()) throw std::invalid_argument("ciphertext does not match the context");
+        PieContext::check(piehip_set_minus_q(cc.handle(), q, minusCompareElement.limbs.data()));
+    }
+    void run()  // BatchedFHEHIPPIE.cpp:88-129 for every query of the batch
+    {
+        PieContext::check(piehip_run(cc.handle()));
+        PieContext::check(piehip_get_results(cc.handle(), results.data()));  // rows [bin layer][query]
+        const size_t ct = ctWords();
+        for (uint32_t q = 0; q < nq; q++)
+            for (uint32_t i = 0; i < b; i++) {
+                const uint64_t *src = &results[((size_t)i * nq + q) * ct];
+                lists[q][i].limbs.assign(src, src + ct);
+            }
+    }
+    std::vector<LimbCt> &getResultList(uint32_t q) { return lists.at(q); }  // the b result ciphertexts of query q
+
+private:
+    size_t ctWords() const { return 2 * (size_t)cc.towers() * cc.ringDimension(); }
+    PieContext &cc;
+    uint32_t K, b, E, nq;
+    std::vector<uint64_t> results, row;
+    std::vector<std::vector<LimbCt>> lists;
 };
 
 }  // namespace piehip

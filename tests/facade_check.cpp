@@ -57,6 +57,40 @@ int main()
                 if (pie.getResultList()[i].limbs != slot.getResultList()[i].limbs) return 4;
             std::printf("query slot ok\n");
         }
+        {
+            // three queries per run() on the same database: each result list equals the single-query operator's
+            PieContext cc3(1024, 2, 65537);
+            BatchedFHEHIPPIEQueryBatch batch(cc3, pie, 3);
+            std::vector<std::vector<LimbCt>> want;
+            for (uint32_t q = 0; q < 3; q++) {
+                LimbCt mq;
+                mq.limbs.assign(ct, 3 + q);
+                std::vector<std::vector<LimbCt>> iq(2, std::vector<LimbCt>(3)), iq2(2, std::vector<LimbCt>(3));
+                for (uint32_t h = 0; h < 2; h++)
+                    for (uint32_t j = 0; j < 3; j++) {
+                        iq[h][j].limbs.assign(ct, 5 + 7 * q + h + 2 * j);
+                        iq2[h][j] = iq[h][j];
+                    }
+                pie.setMinusCompareElement(mq);
+                pie.setIndex(std::move(iq));
+                pie.run();
+                want.push_back(pie.getResultList());
+                batch.setMinusCompareElement(q, mq);
+                batch.setIndex(q, std::move(iq2));
+            }
+            batch.run();
+            for (uint32_t q = 0; q < 3; q++)
+                for (size_t i = 0; i < want[q].size(); i++)
+                    if (batch.getResultList(q)[i].limbs != want[q][i].limbs) return 6;
+            bool refused = false;
+            try {
+                batch.setMinusCompareElement(3, minus);
+            } catch (const std::invalid_argument &) {
+                refused = true;
+            }
+            if (!refused) return 7;
+            std::printf("query batch ok\n");
+        }
         // the rotation-based sibling (FHEHIPPIE.hpp): argument checks, then the reference call order
         CuckooTableView cv;
         cv.numberOfHashFunctions = 2, cv.binSize = 4, cv.eachTableSize = 4;

@@ -9,6 +9,8 @@ mkdir -p $D
 python tools/pmc_summary.py $P/serial/serial_kernel_stats.csv $P/fetch/fetch_counter_collection.csv $P/write/write_counter_collection.csv $P/summary.json
 cp $P/serial/serial_kernel_stats.csv $D/c3_serial_kernel_stats.csv
 cp $P/serial/serial_domain_stats.csv $D/c3_serial_domain_stats.csv
+cp $P/serial1/serial1_kernel_stats.csv $D/c3_serial_one_query_kernel_stats.csv
+cp $P/bench_serial1.json $D/bench_c3_serial_one_query_under_rocprof.json
 cp $P/default/default_kernel_stats.csv $D/c3_default_kernel_stats.csv
 cp $P/default/default_domain_stats.csv $D/c3_default_domain_stats.csv
 cp $P/fetch/fetch_counter_collection.csv $D/c3_pmc_fetch_size.csv
@@ -20,7 +22,7 @@ python - <<PY
 import json
 s = json.load(open("$P/summary.json"))
 s["config"] = "C3"
-s["source"] = ("profiles/$ROUND: tools/profile_round.sh -- rocprofv3 --kernel-trace --stats of 'python3 bench.py --streams 1 --in-flight 1 --no-cpu-baseline --no-e2e' "
+s["source"] = ("profiles/$ROUND: tools/profile_round.sh -- rocprofv3 --kernel-trace --stats of 'python3 bench.py --streams 1 --no-cpu-baseline --no-e2e' (three queries per run()) "
                "(kernel_stats) and separate --pmc FETCH_SIZE / WRITE_SIZE passes of the same command with --steps 5 --warmup 1 --profile-steps 1")
 json.dump(s, open("profiles/latest_pmc.json", "w"), indent=1, sort_keys=True)
 json.dump(s, open("$D/c3_summary.json", "w"), indent=1, sort_keys=True)
