@@ -325,8 +325,10 @@ def projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, steps, wa
     out = {"note": "t(n) = ms per run() over n bin layers on this one GPU; speedup(G) = t(b) / t(ceil(b/G)); excludes the RCCL "
                    "gather of b*2LW result bytes and the query broadcast; cap = b / ceil(b/G).  Two tables: one query at a time "
                    "(latency: the better of eager launches and a replayed hipGraph), and %d queries in flight on query slots "
-                   "(throughput: a rank's small share leaves most of the chip idle, further queries fill it)" % PROJECTION_IN_FLIGHT,
-           "queries_in_flight": PROJECTION_IN_FLIGHT, "rows": {}}
+                   "(throughput: a rank's small share leaves most of the chip idle, further queries fill it); and a third, "
+                   "ms per QUERY with %d queries per run() (query batches) on one handle or on all %d slots, whichever is faster"
+                   % (PROJECTION_IN_FLIGHT, DEFAULT_BATCH, PROJECTION_IN_FLIGHT),
+           "queries_in_flight": PROJECTION_IN_FLIGHT, "queries_per_run_batched": DEFAULT_BATCH, "rows": {}}
     N, L, t = cfg["N"], cfg["L"], cfg["t"]
     sync = lambda: torch.cuda.synchronize(device)
 
@@ -346,7 +348,7 @@ def projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, steps, wa
         b = c2["b"]
         up = upload_ms((c2["K"] * c2["E"] * 2 + 2) * L * N)
         shares = sorted({-(-b // G) for G in (1, 2, 4, 8)}, reverse=True)
-        tms, tfl, graph_better = {}, {}, {}
+        tms, tfl, graph_better, tbq, tbq_slots = {}, {}, {}, {}, {}
         for n in shares:
             stream = torch.cuda.Stream(device)
             cc = pie.PieContext(N, L, t, device=local_rank, stream=stream.cuda_stream)
@@ -364,6 +366,23 @@ def projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, steps, wa
             cc.set_run_streams(1)
             more = make_query_slots(torch, pie, cc, op, (N, L, t, c2["K"], c2["E"]), PROJECTION_IN_FLIGHT, device, local_rank, gen, 1)
             tfl[n] = time_slots([op] + [m[1] for m in more], max(60, steps), max(12, warmup), sync)
+            # query batches: DEFAULT_BATCH queries per run() on every slot; one handle alone (two queues when it has eight or more
+            # layers) or all slots in flight, per query
+            keep = []
+            for o_ in [op] + [m[1] for m in more]:
+                o_.setQueryBatch(DEFAULT_BATCH)
+                for q_ in range(1, DEFAULT_BATCH):
+                    iq = uniform_limbs(torch, (c2["K"], c2["E"], 2), cc.q, N, device, gen)
+                    mq = uniform_limbs(torch, (2,), cc.q, N, device, gen)
+                    keep.append((iq, mq))
+                    o_.setIndexDevice(iq.data_ptr(), query=q_)
+                    o_.setMinusCompareElementDevice(mq.data_ptr(), query=q_)
+            sync()
+            t_all = time_slots([op] + [m[1] for m in more], max(40, steps), max(9, warmup), sync) / DEFAULT_BATCH
+            cc.set_run_streams(0)
+            t_one = time_runs(op, max(40, steps), max(9, warmup), sync) / DEFAULT_BATCH
+            tbq[n], tbq_slots[n] = min(t_all, t_one), (PROJECTION_IN_FLIGHT if t_all <= t_one else 1)
+            del keep
             for m in reversed(more):
                 m[0].close()
             cc.close()
@@ -373,6 +392,9 @@ def projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, steps, wa
                              "speedup": {str(G): tms[b] / tms[-(-b // G)] for G in (2, 4, 8)},
                              "ms_per_run_in_flight": {str(n): tfl[n] for n in shares},
                              "speedup_in_flight": {str(G): tfl[b] / tfl[-(-b // G)] for G in (2, 4, 8)},
+                             "ms_per_query_batched": {str(n): tbq[n] for n in shares},
+                             "batched_runs_in_flight": {str(n): tbq_slots[n] for n in shares},
+                             "speedup_batched": {str(G): tbq[b] / tbq[-(-b // G)] for G in (2, 4, 8)},
                              "cap": {str(G): b / -(-b // G) for G in (2, 4, 8)},
                              # "with query upload": every rank also receives the (K E + 1) query ciphertexts over its own PCIe link
                              # (measured on this GPU, page-locked source).  serial = upload + share, nothing overlapped (one query
@@ -575,14 +597,15 @@ def main():
     # database (3/4 of its traffic) once for the batch, and every later launch carries `batch` times the ciphertexts.
     # Defaults: a batch of three on one handle (one GPU); three slots with one query each where batches do not apply (N > 1:
     # the gather's buffers are per query; --graph; a rank's share of a few bin layers).
-    batching = not (use_dist or args.graph or op is None or args.bins_per_rank)
+    batching = not (args.graph or args.bins_per_rank)
     if args.batch:
-        batch = args.batch if batching else 1
-        in_flight = args.in_flight or 1
+        batch = args.batch if not args.graph else 1
+        in_flight = args.in_flight or (3 if use_dist else 1)
     elif args.in_flight or not batching:
         batch, in_flight = 1, args.in_flight or 3
     else:
-        batch, in_flight = DEFAULT_BATCH, 1
+        # a rank's share of the bin layers is small: batches of three on three slots (projected_strong_scaling measures both)
+        batch, in_flight = DEFAULT_BATCH, (3 if use_dist else 1)
     if args.graph:
         in_flight = 1
     run_streams = args.streams or (1 if in_flight > 1 else 0)
@@ -591,7 +614,7 @@ def main():
     slots = [(cc, op, stream, idx, minus)]
     # (one GPU: two further slots exist in any case -- the legs after the timed region use them -- but only the first
     # `in_flight` take steps)
-    n_slots = max(in_flight, 3) if (batching and not args.no_ref_timer) or (batching and batch > 1) else in_flight
+    n_slots = max(in_flight, 3) if (batching and not use_dist and op is not None) else in_flight
     if n_slots > 1 and op is not None:
         slots += make_query_slots(torch, pie, cc, op, (N, L, t, K, E), n_slots, device, local_rank, gen, args.streams or 1)
     elif n_slots > 1:   # a rank without bin layers still takes part in every slot's collective
@@ -599,6 +622,8 @@ def main():
     extra_inputs = []
     if batch > 1:
         for c_, o_, st_, i_, m_ in slots[:in_flight]:
+            if o_ is None:
+                continue
             o_.setQueryBatch(batch)
             for q_ in range(1, batch):
                 iq = uniform_limbs(torch, (K, E, 2), cc.q, N, device, gen)
@@ -616,7 +641,7 @@ def main():
             times = {}
             for kind in ("gather", "all_gather"):
                 try:
-                    probe = shard.ResultGather(None, b_total, b_local, ct_words, device, stream, kind=kind)
+                    probe = shard.ResultGather(None, b_total, b_local, ct_words * batch, device, stream, kind=kind)
                     for rep in range(6):
                         if rep == 1:
                             torch.cuda.synchronize(device)
@@ -639,16 +664,22 @@ def main():
             if rank == 0:
                 sys.stderr.write("collective timing (5 rounds, s): %s -> %s\n" % (times, args.collective))
         # one double-buffered gather per query slot (slots without bin layers still take part in the collective)
-        rgs = [shard.ResultGather(s_[1], b_total, b_local, ct_words, device, s_[2], kind=args.collective) for s_ in slots]
+        q_words1 = (K * E * 2 + 2) * L * N   # one query: index matrix, then minus element
+        rgs = [shard.ResultGather(s_[1], b_total, b_local, ct_words * batch, device, s_[2], kind=args.collective, batch=batch,
+                                  query_words=q_words1) for s_ in slots]
         rg = rgs[0]
     # Per-query input distribution (N > 1): the query ((K E + 1) ciphertexts) is resident in rank 0's HBM and reaches every rank
     # through the slot's QueryBroadcast inside every step -- the second collective of the sharded server, after
     # which the operator is pointed at the received copy.  --query-source host puts rank 0's copy in page-locked host memory
     # instead (the reference server's situation; PCIe upload inside the step).
-    q_words, q_split = (K * E * 2 + 2) * L * N, K * E * 2 * L * N
+    q_words, q_split = batch * (K * E * 2 + 2) * L * N, K * E * 2 * L * N
     qdist_kind, qdist_times = None, {}
     if use_dist and args.query_dist != "none":
-        flat_q = torch.cat([idx.reshape(-1), minus.reshape(-1)])     # rank 0's copy is the one that counts
+        # rank 0's copy is the one that counts: the `batch` queries of a step one after the other
+        gq = torch.Generator(device=device)
+        gq.manual_seed(24680)
+        flat_q = torch.cat([idx.reshape(-1), minus.reshape(-1)] +
+                           [uniform_limbs(torch, shp, cc.q, N, device, gq).reshape(-1) for _ in range(1, batch) for shp in ((K, E, 2), (2,))])
         flat_h = flat_q.cpu().pin_memory() if args.query_source == "host" else None
         kinds = ["broadcast", "scatter_gather"] if args.query_dist == "auto" else [args.query_dist]
         if args.rehearse_on_one_gpu:
@@ -775,7 +806,8 @@ def main():
 
     if batch > 1:   # the legs below take one query per run()
         for c_, o_, st_, i_, m_ in slots[:in_flight]:
-            o_.setQueryBatch(1)
+            if o_ is not None:
+                o_.setQueryBatch(1)
     if rank == 0:
         value = batch * b_total / (ms_per_step * 1e-3)
         cname = "C4 (C3's bin layers over %d GPUs)" % world if (world > 1 and scaling == "strong" and args.config == "C3") else args.config

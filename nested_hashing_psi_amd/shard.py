@@ -192,11 +192,18 @@ class ResultGather:
     buffers on the same stream and the host waits for that copy before the gather.
     """
 
-    def __init__(self, op, b, b_local, ct_words, device, stream, kind="gather", dst=0, group=None, query=None, query_split=None):
+    def __init__(self, op, b, b_local, ct_words, device, stream, kind="gather", dst=0, group=None, query=None, query_split=None,
+                 batch=1, query_words=None):
         """query: a QueryBroadcast -- step() then first distributes the next query from rank dst and points the operator at the
-        received copy; query_split = words of the index matrix (the minus element follows it in the flat array)"""
+        received copy; query_split = words of the index matrix (the minus element follows it in the flat array).
+        batch > 1: the operator evaluates `batch` queries per run() (setQueryBatch); the distributed array holds them one after
+        the other, query_words each (index matrix, then minus element), and a "ciphertext" row of the gather is the `batch`
+        result ciphertexts of one bin layer (ct_words = batch * 2 L N: the library's rows are [bin layer][query])"""
         self.op, self.b, self.dst, self.kind, self.group = op, b, dst, kind, group
         self.query, self.query_split = query, query_split
+        self.batch, self.query_words = batch, query_words
+        if batch > 1 and query is not None and query_words is None:
+            raise ValueError("a query batch needs query_words (words per query in the distributed array)")
         self.run_done = [torch.cuda.Event(), torch.cuda.Event()]
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -232,8 +239,10 @@ class ResultGather:
             if self.query is not None:
                 flat = self.query.ready(s, self.stream)
                 if self.op is not None and self.b_local:
-                    self.op.setIndexDevice(flat.data_ptr())
-                    self.op.setMinusCompareElementDevice(flat.data_ptr() + 8 * self.query_split)
+                    for q in range(self.batch):
+                        base = flat.data_ptr() + 8 * q * (self.query_words or 0)
+                        self.op.setIndexDevice(base, query=q)
+                        self.op.setMinusCompareElementDevice(base + 8 * self.query_split, query=q)
             if self.op is not None and self.b_local:
                 self.op.run(sync=False, into=self.my_out[s].data_ptr())
                 self.op.join()

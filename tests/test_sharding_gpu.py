@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, backend, b, nq, q, nslots=1):
+def _worker(rank, world, port, backend, b, nq, q, nslots=1, batch=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -51,7 +51,8 @@ def _worker(rank, world, port, backend, b, nq, q, nslots=1):
         stream = torch.cuda.Stream(device)
         cc = pie.PieContext(N, L, t, device=0, stream=stream.cuda_stream)
         db, masks, evk = rl((K, b, E), cc.q), rl((b,), cc.q), rl((L, 2), cc.q)
-        queries = [(rl((K, E, 2), cc.q), rl((2,), cc.q)) for _ in range(nq)]
+        # nq steps of `batch` queries each (batch > 1: query batches, piehip_set_query_batch -- bench.py's N > 1 path)
+        queries = [[(rl((K, E, 2), cc.q), rl((2,), cc.q)) for _ in range(batch)] for _ in range(nq)]
         if rank != 0:
             queries = [None] * nq     # only rank 0 (the rank that talks to the client) knows the queries
         cc.load_relin_key(evk)
@@ -68,14 +69,18 @@ def _worker(rank, world, port, backend, b, nq, q, nslots=1):
             cc_ = cc if s_ == 0 else pie.PieContext(N, L, t, device=0, stream=st_.cuda_stream)
             op_ = op if s_ == 0 else (pie.BatchedFHEHIPPIE(cc_, attachTo=op) if op is not None else None)
             q_split = K * E * 2 * L * N
-            qb = shard.QueryBroadcast(q_split + 2 * L * N, device, src=0, kind="broadcast")
+            q_words = q_split + 2 * L * N
+            if op_ is not None and batch > 1:
+                op_.setQueryBatch(batch)
+            qb = shard.QueryBroadcast(batch * q_words, device, src=0, kind="broadcast")
             slots.append(dict(cc=cc_, op=op_, stream=st_, qb=qb,
-                              rg=shard.ResultGather(op_, b, hi - lo, ct_words, device, st_, kind="gather", query=qb, query_split=q_split)))
+                              rg=shard.ResultGather(op_, b, hi - lo, batch * ct_words, device, st_, kind="gather", query=qb,
+                                                    query_split=q_split, batch=batch, query_words=q_words)))
         got, keep = [], []
         for i, query in enumerate(queries):
             sl = slots[i % nslots]
             if rank == 0:   # the query in page-locked host memory, one array per query (the upload is asynchronous)
-                flat = torch.from_numpy(np.concatenate([query[0].reshape(-1), query[1].reshape(-1)]).view(np.int64)).pin_memory()
+                flat = torch.from_numpy(np.concatenate([part.reshape(-1) for one in query for part in one]).view(np.int64)).pin_memory()
                 keep.append(flat)
                 sl["qb"].set_query_host(flat)
             got.append((sl, sl["rg"].step()))
@@ -90,15 +95,19 @@ def _worker(rank, world, port, backend, b, nq, q, nslots=1):
             cc1.load_relin_key(evk)
             full = pie.BatchedFHEHIPPIE(cc1, vectorizedHCT=db, preCalcRandomMask=masks)
             for i in range(max(0, nq - 2 * nslots), nq):
-                idx, minus = queries[i]
-                full.setMinusCompareElement(minus)
-                full.setIndex(idx)
-                full.run()
-                want = full.getResultList().reshape(b, ct_words).view(np.int64)
-                rows = got[i][0]["rg"].rows(got[i][1]).cpu().numpy()
-                if rows.shape != want.shape or not (rows == want).all():
+                rows = got[i][0]["rg"].rows(got[i][1]).cpu().numpy()      # [b][batch * ct_words]: a bin layer's results, query by query
+                if rows.shape != (b, batch * ct_words):
                     ok = False
-                    detail += "query %d differs; " % i
+                    detail += "step %d: shape %s; " % (i, rows.shape)
+                    continue
+                for j, (idx, minus) in enumerate(queries[i]):
+                    full.setMinusCompareElement(minus)
+                    full.setIndex(idx)
+                    full.run()
+                    want = full.getResultList().reshape(b, ct_words).view(np.int64)
+                    if not (rows[:, j * ct_words:(j + 1) * ct_words] == want).all():
+                        ok = False
+                        detail += "step %d query %d differs; " % (i, j)
             cc1.close()
         for sl in reversed(slots):
             sl["cc"].close()
@@ -113,12 +122,12 @@ def _worker(rank, world, port, backend, b, nq, q, nslots=1):
             pass
 
 
-def _run(world, backend, b, nq=5, nslots=1):
+def _run(world, backend, b, nq=5, nslots=1, batch=1):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, b, nq, q, nslots)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, b, nq, q, nslots, batch)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(world)]
@@ -139,10 +148,19 @@ def test_sharded_ranks_with_query_slots():
     _run(2, "gloo", 7, nq=9, nslots=3)
 
 
+def test_sharded_ranks_with_query_batches():
+    """bench.py's default N > 1 step: three queries per run() (piehip_set_query_batch) on three query slots per rank; the
+    distributed array holds the batch's queries one after the other, a gathered row the batch's results of one bin layer.
+    Every query against the unsharded, one-query-per-run evaluation (gloo; b = 14 over four ranks is 3 + 4 + 3 + 4)."""
+    _run(2, "gloo", 7, nq=7, nslots=3, batch=3)
+    _run(4, "gloo", 14, nq=4, nslots=1, batch=2)
+
+
 def test_one_rank_rccl_device_gather():
     """the RCCL form of the same sequence (device tensors, asynchronous gather on RCCL's stream), also over three slots"""
     _run(1, "nccl", 6)
     _run(1, "nccl", 6, nq=7, nslots=3)
+    _run(1, "nccl", 6, nq=5, nslots=2, batch=3)
 
 
 # ---- C4 at its real shape, against the oracle ------------------------------------------------------------------------------
