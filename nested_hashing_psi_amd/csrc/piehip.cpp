@@ -1332,6 +1332,7 @@ int piehip_run_into(piehip_handle h, void *d_results)
     if (!h) return fail(PIEHIP_EINVAL, "null handle");
     if (!d_results) return fail(PIEHIP_EINVAL, "null result buffer");
     if (!h->K || !h->d_db) return fail(PIEHIP_ESTATE, "run: database not loaded");
+    if (!h->d_acc || !h->ws.eqp) return fail(PIEHIP_ESTATE, "run: no workspace (an earlier allocation failed: piehip_set_query_batch / load)");
     if (!h->d_evk && h->K > 1) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
     if (!h->d_idx || !h->d_minus) return fail(PIEHIP_ESTATE, "run: setIndex / setMinusCompareElement not called");
     for (u32 q = 1; q < h->nq; q++)
