@@ -149,18 +149,21 @@ __device__ __forceinline__ u64 uniform_addr(const void *p)  // (uniform integer 
     return ((u64)hi << 32) | lo;
 }
 
-// x in [0, 2m) -> [0, m) with the NEGATED modulus (2^64 - m): t = x - m as one v_lshl_add_u64, then a select on the sign of t
-// (v_ashrrev_i32 + two v_bfi_b32): 4 instructions where hipcc's `x >= m ? x - m : x` is compare + subtract pair + two
-// v_cndmask_b32 through VCC with its wait states.
+// x in [0, 2m) -> [0, m) with the NEGATED modulus (2^64 - m), wave-uniform: t = x - m as one v_lshl_add_u64, then a select on
+// the sign of t (v_ashrrev_i32 + two v_bfi_b32): 4 instructions.  hipcc's `x >= m ? x - m : x` is compare + subtract pair +
+// two v_cndmask_b32 through VCC with its wait states, and `x + negm` in C++ becomes v_subrev_co / s_nop 1 / v_subb_co with the
+// high word of the constant moved into a vector register first -- the whole step inside one statement avoids both.  (The
+// temporaries are three of the butterfly blocks' fixed registers.)
 __device__ __forceinline__ u64 csub_neg(u64 x, u64 negm)
 {
-    const u64 t = x + negm;
-    u32 lo, hi, k;
-    asm("v_ashrrev_i32 %[k], 31, %[th]\n\t"
-        "v_bfi_b32 %[lo], %[k], %[xl], %[tl]\n\t"
-        "v_bfi_b32 %[hi], %[k], %[xh], %[th]"
-        : [lo] "=&v"(lo), [hi] "=&v"(hi), [k] "=&v"(k)
-        : [xl] "v"((u32)x), [xh] "v"((u32)(x >> 32)), [tl] "v"((u32)t), [th] "v"((u32)(t >> 32)));
+    u32 lo, hi;
+    asm("v_lshl_add_u64 v[126:127], %[x], 0, %[nm]\n\t"
+        "v_ashrrev_i32 v125, 31, v127\n\t"
+        "v_bfi_b32 %[lo], v125, %[xl], v126\n\t"
+        "v_bfi_b32 %[hi], v125, %[xh], v127"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi)
+        : [x] "v"(x), [xl] "v"((u32)x), [xh] "v"((u32)(x >> 32)), [nm] "s"(negm)
+        : "v125", "v126", "v127");
     return ((u64)hi << 32) | lo;
 }
 
