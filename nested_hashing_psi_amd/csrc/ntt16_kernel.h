@@ -360,20 +360,25 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
             NTT16_PRIO_F(0);
             // ---- pass 1: rows r = 0..7 (bits 12..10) of the column pair -------------------------------------------------
             if (lift) {
-                // equal-width primes (q_i < 2 q_j for every pair: the host checks): a conditional subtraction reduces a residue
-                // mod q_i into q_j, and residues above q_i / 2 are corrected by q_i mod q_j (centred lift, kernels_pie.hip)
+                // Centred lift of a residue v of q_i into q_j for equal-width primes (q_i < 2 q_j for every pair: the host checks):
+                // the centred representative v - [v > q_i / 2] q_i lies in (-q_j, q_j), so its residue mod q_j is v itself for
+                // v <= floor(q_i / 2) and v + (q_j - q_i) above -- one masked 64-bit add, canonical result (five instructions; the
+                // formulation it replaces reduced v mod q_j first and corrected by q_i mod q_j with a sign fix-up: fourteen).
                 const u32 LL = a.lift_L, li = __builtin_amdgcn_readfirstlane((limb / LL) % LL), lj = __builtin_amdgcn_readfirstlane(limb % LL);
                 const u64 *src = a.lift_src + (size_t)(limb / (LL * LL)) * a.lift_stride + (size_t)li * a.N;
-                const u64 qh = dcs->mod[li].q / 2, qq = dcs->qi_modqj[li][lj];
-                const u64 nq1 = 0 - q, nqh1 = 0 - (qh + 1);
+                const u64 qi = dcs->mod[li].q;
+                const u64 nqh1 = 0 - (qi / 2 + 1), dq = q - qi;
                 auto lift1 = [&](u64 v) -> u64 {
-                    const u64 r = csub_neg(v, nq1);               // v mod q_j
-                    // centred correction: subtract q_i mod q_j when v > q_i / 2 (mask from the sign of v - (qh + 1))
-                    const u32 neg = (u32)((int32_t)((v + nqh1) >> 32) >> 31);    // ~0 when v <= qh
-                    const u64 c = qq & ~(((u64)neg << 32) | neg);
-                    const u64 d = r - c;                           // in (-q, q)
-                    const u32 dn = (u32)((int32_t)(d >> 32) >> 31);              // ~0 when negative
-                    return d + (q & (((u64)dn << 32) | dn));
+                    u64 r;
+                    asm("v_lshl_add_u64 v[126:127], %[v], 0, %[nqh1]\n\t"   // v - (floor(q_i / 2) + 1): negative iff v <= floor(q_i / 2)
+                        "v_ashrrev_i32 v125, 31, v127\n\t"
+                        "v_bfi_b32 v126, v125, 0, %[dql]\n\t"               // q_j - q_i where v is above the half, 0 otherwise
+                        "v_bfi_b32 v127, v125, 0, %[dqh]\n\t"
+                        "v_lshl_add_u64 %[r], %[v], 0, v[126:127]"
+                        : [r] "=v"(r)
+                        : [v] "v"(v), [nqh1] "s"(nqh1), [dql] "s"((u32)dq), [dqh] "s"((u32)(dq >> 32))
+                        : "v125", "v126", "v127");
+                    return r;
                 };
                 if (a.s0 == 1) {
                     // two folded slices per limb: the outermost stage (u, v) -> (u + v psi^{N/2}, u - v psi^{N/2}) is one more
