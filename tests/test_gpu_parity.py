@@ -695,6 +695,8 @@ def test_caller_supplied_moduli(ob, pie, N, L, t, below, what):
     (2048, 3, T32, 3, 17, 4, (2, 7)),              # K = 3 (two chained products), E > 15: carry sweeps and a mid-sum reduction
     (4096, 2, T16, 1, 6, 3, (2, 4)),               # K = 1: stage A + mask multiply
     (8192, 3, T32, 2, 4, 7, (6,)),                 # 3 + 3 queries, b = 7: 4 + 3 / 2 + 2 + 2 + 1 layers per thread
+    (16384, 4, T32, 2, 14, 1, (3,)),               # one bin layer: a rank's share of b = 14 over eight GPUs
+    (16384, 4, T32, 2, 14, 2, (3,)),               # ... and two
 ])
 def test_query_batches(ob, pie, N, L, t, K, E, b, nqs):
     """piehip_set_query_batch: run() over nq queries at once.  Every query's ciphertexts equal the oracle's for that query alone
