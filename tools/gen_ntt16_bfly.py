@@ -5,12 +5,13 @@ gfx950 instruction blocks (the generator can interleave NB independent butterfli
 Issue costs on gfx950 (tools/microbench_ops.hip, cycles per wave64 instruction per SIMD with 2+ waves): every VOP3 instruction --
 v_mad_u64_u32, v_lshl_add_u64, v_lshrrev_b64, v_bfi_b32, v_mul_lo/hi_u32 alike -- 4.1-4.3; 32-bit VOP1/VOP2 2.0-2.5; a wave
 alone on its SIMD 4+ for everything; a 2-cycle instruction that follows a 4-cycle one costs 4 itself (tools/microbench_operands.hip), so
-the VOP1/VOP2 instructions are grouped.  Forward block 21 instructions, inverse 22 (its last product is written straight to the output).
+the VOP1/VOP2 instructions are grouped.  Both blocks are 20 instructions, 19 where 2 sh is an operand (the inverse's last product is
+written straight to the output; 64-bit differences are borrow chains through VCC, see ct_stream).
 
     python tools/gen_ntt16_bfly.py          (rewrites the .inc; the output is committed)
 
-Register use of stream i: n = 11 (forward) or 13 (inverse) fixed VGPRs v[128 - n (i + 1) .. 128 - n i) (an asm operand cannot name the halves of a
-64-bit pair, so every temporary whose halves are needed lives in a named register; all are in the clobber list).
+Register use of stream i: 11 fixed VGPRs v[128 - 11 (i + 1) .. 128 - 11 i) (an asm operand cannot name the halves of a 64-bit pair, so every
+temporary whose halves are needed lives in a named register; all are in the clobber list).
 """
 import os
 
