@@ -134,7 +134,7 @@ int piehip_set_minus_device(piehip_handle h, const void *d_minus);
  * multipliedResult is the inner product itself (.cpp:117-120), so run() is stage A and the mask multiply (.cpp:126); no key needed. */
 int piehip_run(piehip_handle h);
 /* the same, with the result ciphertexts written straight into caller-owned HBM d_results[b][2][L][N] (e.g. the RCCL
- * gather buffer) instead of the handle's result buffer */
+ * gather buffer; d_results[b][nq][2][L][N] for a query batch) instead of the handle's result buffer */
 int piehip_run_into(piehip_handle h, void *d_results);
 /* The online phase in one call, as the reference server times it (BatchedFHEPSIServer.cpp:98-108): setMinusCompareElement +
  * setIndex + run + getResultList with the query in HOST memory.  The index matrix is uploaded one inner hash function (row of
@@ -209,7 +209,8 @@ int piehip_set_index_device_q(piehip_handle h, uint32_t q, const void *d_idx);
 int piehip_set_minus_device_q(piehip_handle h, uint32_t q, const void *d_minus);
 /* getResultList (BatchedFHEHIPPIE.hpp:35-38): out[b][2][L][N] (out[b][nq][2][L][N] for a query batch) */
 int piehip_get_results(piehip_handle h, uint64_t *out);
-/* device address of the result buffer [b][2][L][N] (valid until destroy); for the RCCL gather */
+/* device address of the result buffer [b][2][L][N] ([b][nq][2][L][N] for a query batch; valid until the database shape or the
+ * batch size changes); for the RCCL gather */
 int piehip_results_device(piehip_handle h, void **d_out);
 /* enqueue a device-to-device copy of the results into caller-owned HBM (e.g. the RCCL gather buffer) */
 int piehip_copy_results_device(piehip_handle h, void *d_dst);
