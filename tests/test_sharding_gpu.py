@@ -232,7 +232,7 @@ def _c3_check(ob, o, sk, query, rows, want):
     assert sorted(int(v) for v in found) == sorted(int(v) for v in query["inter"])
 
 
-def _c4_worker(rank, world, port, q, nslots):
+def _c4_worker(rank, world, port, q, nslots, batch=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -264,21 +264,27 @@ def _c4_worker(rank, world, port, q, nslots):
         if rank == 0 and not (op.hashTable() == side[1]).all():
             ok, detail = False, "hash table differs from the oracle's; "
         q_split = K * E * 2 * L * N
+        q_words = q_split + ct_words          # one query in the distributed array: index matrix, then minus element
         slots = []
         for s_ in range(nslots):
             st_ = stream if s_ == 0 else torch.cuda.Stream(device)
             cc_ = cc if s_ == 0 else pie.PieContext(N, L, t, device=0, stream=st_.cuda_stream)
             op_ = op if s_ == 0 else pie.BatchedFHEHIPPIE(cc_, attachTo=op)
-            qb = shard.QueryBroadcast(q_split + ct_words, device, src=0, kind="broadcast")
-            slots.append(dict(cc=cc_, qb=qb, rg=shard.ResultGather(op_, b, hi - lo, ct_words, device, st_, kind="gather", query=qb,
-                                                                   query_split=q_split)))
+            if batch > 1:
+                op_.setQueryBatch(batch)      # a step of this slot evaluates `batch` queries (bench.py's N > 1 default: 3 on 3 slots)
+            qb = shard.QueryBroadcast(batch * q_words, device, src=0, kind="broadcast")
+            slots.append(dict(cc=cc_, qb=qb, rg=shard.ResultGather(op_, b, hi - lo, batch * ct_words, device, st_, kind="gather", query=qb,
+                                                                   query_split=q_split, batch=batch, query_words=q_words)))
         nq = 2 * nslots + 1                   # every slot uses both of its buffer sets; consecutive queries differ
         got, keep = [], []
         for i in range(nq):
             sl = slots[i % nslots]
             if rank == 0:
-                qy = side[6][i % 2]
-                flat = torch.from_numpy(np.concatenate([qy["idx"].reshape(-1), qy["minus"].reshape(-1)]).view(np.int64)).pin_memory()
+                parts = []
+                for j in range(batch):        # the queries of a step alternate between the two clients, starting with i
+                    qy = side[6][(i + j) % 2]
+                    parts += [qy["idx"].reshape(-1), qy["minus"].reshape(-1)]
+                flat = torch.from_numpy(np.concatenate(parts).view(np.int64)).pin_memory()
                 keep.append(flat)
                 sl["qb"].set_query_host(flat)
             got.append((sl, sl["rg"].step()))
@@ -289,13 +295,14 @@ def _c4_worker(rank, world, port, q, nslots):
             from oracle import binding as ob
             o, tbl, oslots, mask_slots, sk, evk, queries = side
             want = [_c3_oracle_results(ob, o, oslots, mask_slots, evk, qy) for qy in queries]
-            for i in range(max(0, nq - 2 * nslots), nq):    # the last two queries of every slot are still in its buffer sets
-                rows = got[i][0]["rg"].rows(got[i][1]).cpu().numpy().view(np.uint64).reshape(b, 2, L, N)
-                try:
-                    _c3_check(ob, o, sk, queries[i % 2], rows, want[i % 2])
-                except AssertionError as exc:
-                    ok = False
-                    detail += "query %d: %s; " % (i, exc)
+            for i in range(max(0, nq - 2 * nslots), nq):    # the last two steps of every slot are still in its buffer sets
+                allrows = got[i][0]["rg"].rows(got[i][1]).cpu().numpy().view(np.uint64).reshape(b, batch, 2, L, N)
+                for j in range(batch):
+                    try:
+                        _c3_check(ob, o, sk, queries[(i + j) % 2], np.ascontiguousarray(allrows[:, j]), want[(i + j) % 2])
+                    except AssertionError as exc:
+                        ok = False
+                        detail += "step %d query %d: %s; " % (i, j, exc)
         for sl in reversed(slots):
             sl["cc"].close()
         q.put((rank, ok, detail))
@@ -309,18 +316,19 @@ def _c4_worker(rank, world, port, q, nslots):
             pass
 
 
-@pytest.mark.parametrize("world", [2, 4, 5])
-def test_c4_real_shape_against_the_oracle(world):
+@pytest.mark.parametrize("world,batch", [(2, 1), (4, 1), (5, 1), (4, 3)])
+def test_c4_real_shape_against_the_oracle(world, batch):
     """BASELINE config C4 (C3's 14 bin layers over `world` ranks: 7+7, 3+4+3+4, 2+3+3+3+3), three query slots per rank, real
     secret-key encrypted queries that only rank 0 holds, every rank's database slice built by piehip_build_db_bins from the
     raw server set: rank 0's gathered rows equal the oracle's run() on all 14 layers and decrypt to the 513-item
     intersection.  The ranks share the one GPU of the test box and talk over gloo; the box admits six processes on one card
-    (five ranks + this test runner; 8 slices: test_c4_eight_bin_slices_in_one_process)."""
+    (five ranks + this test runner; 8 slices: test_c4_eight_bin_slices_in_one_process).  batch = 3: every step of a slot is a
+    batch of three queries (piehip_set_query_batch), the N > 1 step of bench.py; each query of each batch against the oracle."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_c4_worker, args=(r, world, port, q, 3)) for r in range(world)]
+    procs = [ctx.Process(target=_c4_worker, args=(r, world, port, q, 3, batch)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in range(world)]
