@@ -385,7 +385,7 @@ void launch_stage_a_batch(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E
     while (small_moduli && nq - q0 >= 2) {
         // groups of four, three or two queries (five: 3 + 2; six: 3 + 3; seven: 4 + 3)
         const u32 left = nq - q0, g = left == 5 || left == 6 ? 3 : std::min(left, 4u);
-        StageAQueries sub;
+        StageAQueries sub = {};
         for (u32 q = 0; q < g; q++) sub.idx[q] = qs.idx[q0 + q], sub.minus[q] = qs.minus[q0 + q];
         if (g == 2) launch_stage_a_batch_q<2>(dc, N, L, K, b, E, sub, db, acc, st, bstride, h0, hn, nq, q0);
         else if (g == 3) launch_stage_a_batch_q<3>(dc, N, L, K, b, E, sub, db, acc, st, bstride, h0, hn, nq, q0);

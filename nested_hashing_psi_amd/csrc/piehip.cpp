@@ -1280,7 +1280,7 @@ static void enqueue_run_bins(piehip_ctx *h, u32 b0, u32 nb, u64 *results)
     {   // stage A: all inner products of these bin layers in one launch (BatchedFHEHIPPIE.cpp:101-116)
         ProfScope ps(h, PIEHIP_K_STAGE_A, W * ((double)layers * K * E * L + nq * ((double)K * E * 2 * L + 2.0 * L + (double)layers * K * 2 * L)));
         if (nq > 1) {
-            StageAQueries qs;
+            StageAQueries qs = {};
             qs.idx[0] = h->d_idx, qs.minus[0] = h->d_minus;
             for (u32 q = 1; q < nq; q++) qs.idx[q] = h->bq_idx[q], qs.minus[q] = h->bq_minus[q];
             launch_stage_a_batch(h->d_dc, N, L, K, layers, E, qs, nq, h->d_db + (size_t)b0 * E * LN, acc, h->stream, h->small_moduli, b);

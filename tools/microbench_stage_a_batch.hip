@@ -17,7 +17,7 @@ static DevConsts *g_dc;
 template <int BPT, int Q, int DEPTH>
 static void run(bool same_idx)
 {
-    StageAQueries qs;
+    StageAQueries qs = {};
     for (int q = 0; q < Q; q++) qs.idx[q] = g_idx[same_idx ? 0 : q], qs.minus[q] = g_minus;
     const u32 nx = N / TPB, tiles = nx * L * K;
     const dim3 grid = stage_a_grid(nx, L, K, B / BPT);
