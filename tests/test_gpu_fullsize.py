@@ -13,6 +13,8 @@ parity with OpenFHE itself is unpinned.
   C1  N=4096,  2 primes, t=65537,      |S|=2^12, |C|=2^8,  k=3 e=110   K=2 E=7  b=7    (derived)
   C2  N=8192,  3 primes, t=4296540161, |S|=2^16, |C|=2^10, k=3 e=443   K=2 E=12 b=12   (Parameters1.txt:53)
   C3  N=16384, 4 primes,               |S|=2^20, |C|=2^10, k=2 e=4949  K=2 E=14 b=14   (Parameters1.txt:11)
+      + the same database with THREE different queries in one run() on one handle: bench.py's default timed region
+      + the reference's alternative row for these set sizes, E=20 b=10 (Parameters1.txt:35)
   C5  N=32768, 6 primes,               |S|=2^24, |C|=2^12, k=2 e=13004 K=3 E=30 b=30   (Parameters1.txt:19 with -K 3)
   KAT-0 at the reference test's own parameters: tests/TestBatchedFHEPIE.cpp:14-41,89-94 (N=16384, 33-bit t).
 C4 (C3's bin layers over several GPUs) is tests/test_sharding_gpu.py.
@@ -26,61 +28,80 @@ T32 = 4296540161
 SEEDS = dict(hash_seed=987654321, evict_seed=1, shuffle_seed=2, mask_seed=3)
 
 
-def run_case(ob, pie, N, L, t, nS, nC, k, e, K, E, b, seed, compare_layers, streams=0):
+def run_case(ob, pie, N, L, t, nS, nC, k, e, K, E, b, seed, compare_layers, streams=0, nq=1):
+    """nq > 1: nq DIFFERENT clients (own item sets, own Cuckoo tables, own encryption randomness -- one key, as the operator
+    holds one EvalMult key) are evaluated by ONE run() on one handle (setQueryBatch); every query's result list is checked
+    as if it had been run alone."""
     o = ob.Oracle(N, L, t)
     rng = np.random.default_rng(seed)
-    items = np.unique(rng.integers(1, t, nS + nC + 4096, dtype=np.uint64))
+    items = np.unique(rng.integers(1, t, nS + nq * nC + 4096, dtype=np.uint64))
     rng.shuffle(items)
     server = items[:nS].copy()
     ninter = nC // 2 + 1
-    client = np.concatenate([server[:ninter], items[nS:nS + nC - ninter]])
-    rng.shuffle(client)
     # oracle side of the offline phase
     tab = ob.Tabulation(SEEDS["hash_seed"], k + K)
     tbl = ob.hct_build(tab, server, k, e, K, b, E, evict_seed=SEEDS["evict_seed"])
     ob.hct_shuffle_bins(tbl, SEEDS["shuffle_seed"])
     slots = ob.pack_db(tbl)
     mask_slots = ob.masks(t, b, k * e, SEEDS["mask_seed"])
-    # client
-    ctab = ob.client_build(tab, client, k, e, evict_seed=4)
-    index, minus_v = ob.client_vectors(tab, ctab, K, E)
+    # clients: query q shares items [q * 97, q * 97 + ninter) of the server set and brings nC - ninter of its own
     sk = o.keygen(11)
     evk = o.relin_keygen(sk, 12)
-    idx = np.stack([o.encrypt_slots(sk, index[h, j], 100 + h * E + j) for h in range(K) for j in range(E)]).reshape(K, E, 2, L, N)
-    minus = o.encrypt_slots(sk, minus_v, 99)
-    # device: whole offline phase from the raw server set, then the query
+    queries = []
+    for q in range(nq):
+        inter = server[q * 97:q * 97 + ninter]
+        client = np.concatenate([inter, items[nS + q * nC:nS + q * nC + nC - ninter]])
+        rng.shuffle(client)
+        ctab = ob.client_build(tab, client, k, e, evict_seed=4 + q)
+        index, minus_v = ob.client_vectors(tab, ctab, K, E)
+        idx = np.stack([o.encrypt_slots(sk, index[h, j], 100 + 1000 * q + h * E + j) for h in range(K) for j in range(E)]).reshape(K, E, 2, L, N)
+        minus = o.encrypt_slots(sk, minus_v, 99 + 1000 * q)
+        queries.append((inter, ctab, idx, minus))
+    # device: whole offline phase from the raw server set, then the queries
     cc = pie.PieContext(N, L, t)
     cc.load_relin_key(evk)
     cc.set_run_streams(streams)
     op = pie.BatchedFHEHIPPIE(cc, serverSet=server, hashParams=dict(k=k, e=e, K=K, b=b, E=E, **SEEDS))
     assert (op.hashTable() == tbl).all()
     del tbl
-    op.setMinusCompareElement(minus)
-    op.setIndex(idx)
+    if nq > 1:
+        op.setQueryBatch(nq)
+    for q, (_, _, idx, minus) in enumerate(queries):
+        op.setMinusCompareElement(minus, query=q)
+        op.setIndex(idx, query=q)
     op.run()
     got = op.getResultList().copy()
     cc.close()
-    # (b) decrypted semantics on every bin layer
-    dec, budgets = [], []
-    for bn in range(b):
-        d, bud = o.decrypt_slots(sk, got[bn], k * e)
-        dec.append(d)
-        budgets.append(bud)
+    if nq == 1:
+        got = got[None]
+    assert got.shape == (nq, b, 2, L, N)
+    # (b) decrypted semantics on every bin layer of every query
+    budgets = []
+    for q, (inter, ctab, _, _) in enumerate(queries):
+        dec = []
+        for bn in range(b):
+            d, bud = o.decrypt_slots(sk, got[q, bn], k * e)
+            dec.append(d)
+            budgets.append(bud)
+        found = ob.client_scan(ctab, np.stack(dec))
+        assert len(found) == ninter
+        assert sorted(int(v) for v in found) == sorted(int(v) for v in inter)
     assert min(budgets) > 0
-    found = ob.client_scan(ctab, np.stack(dec))
-    assert len(found) == ninter
-    assert sorted(int(v) for v in found) == sorted(int(v) for v in server[:ninter])
     # (a) ciphertext bits: bin layers are independent, one oracle task each (the C calls release the GIL)
     import concurrent.futures
 
     def layer_differs(bn):
         db = np.stack([o.encode_eval(slots[h, bn, j]) for h in range(K) for j in range(E)]).reshape(K, 1, E, L, N)
         masks = o.encode_eval(mask_slots[bn])[None]
-        want = o.pie_run(idx, minus, db, masks, evk)
-        return bn if not (got[bn] == want[0]).all() else None
+        bad = []
+        for q, (_, _, idx, minus) in enumerate(queries):
+            want = o.pie_run(idx, minus, db, masks, evk)
+            if not (got[q, bn] == want[0]).all():
+                bad.append((q, bn))
+        return bad
     with concurrent.futures.ThreadPoolExecutor(max_workers=12) as pool:
-        bad = [bn for bn in pool.map(layer_differs, list(compare_layers)) if bn is not None]
-    assert not bad, "bin layers %s differ from the oracle" % bad
+        bad = [x for r in pool.map(layer_differs, list(compare_layers)) for x in r]
+    assert not bad, "(query, bin layer) pairs %s differ from the oracle" % bad
     return min(budgets)
 
 
@@ -99,6 +120,27 @@ def test_c3_headline_config_all_layers(ob, pie_mod):
 def test_c3_serial_queue_all_layers(ob, pie_mod):
     """the same query with run() on one queue (what bench.py --streams 1 and the per-kernel profile passes execute)"""
     run_case(ob, pie_mod, 16384, 4, T32, 1 << 20, 1 << 10, 2, 4949, 2, 14, 14, 123456789, range(14), streams=1)
+
+
+@pytest.mark.parametrize("streams", [0, 1])
+def test_c3_headline_batch_of_three(ob, pie_mod, streams):
+    """bench.py's default timed region itself: C3 with setQueryBatch(3) on ONE handle (b = 14, E = 14 -> stage_a_mad_batch_kernel<2,3>
+    over seven layer pairs; transform launches of 1 344 / 2 352 / 2 268 / 2 016 slices), three different real queries, on two queues
+    (8 + 6 bin layers, the default) and on one (bench.py --streams 1, the per-kernel profile passes): every query's 14 result
+    ciphertexts equal the oracle's run() of that query alone, and each decrypts to its own client's intersection."""
+    run_case(ob, pie_mod, 16384, 4, T32, 1 << 20, 1 << 10, 2, 4949, 2, 14, 14, 20261005, range(14), streams=streams, nq=3)
+
+
+def test_c3_alternative_row_e20_b10(ob, pie_mod):
+    """The reference's second parameter row for |S| = 2^20, |C| = 2^10 (Performance-Evaluation/Parameters1.txt:35: maxPP 10,
+    eachCuckooTableSize 20): E = 20 crosses the 15-term renormalisation of stage A's carry-free column accumulators at the real
+    ring size; 10 bin layers on two queues (6 + 4)."""
+    run_case(ob, pie_mod, 16384, 4, T32, 1 << 20, 1 << 10, 2, 4949, 2, 20, 10, 35, range(10))
+
+
+def test_c3_alternative_row_batch_of_three(ob, pie_mod):
+    """the same row as a batch of three queries per run() (E = 20 in the batched stage A: two accumulator sweeps per thread)"""
+    run_case(ob, pie_mod, 16384, 4, T32, 1 << 20, 1 << 10, 2, 4949, 2, 20, 10, 36, range(10), nq=3)
 
 
 def test_c5_full_size(ob, pie_mod):
