@@ -1,183 +1,46 @@
-// piehip.cpp -- C ABI (include/piehip.h) over the gfx950 kernels: device memory, streams, the
-// launch schedule of BatchedFHEHIPPIE::run() (reference BatchedFHEHIPPIE.cpp:88-129) and the
-// kernel-level entry points used by the parity tests.
-#include "../../include/piehip.h"
-
-#include <hip/hip_runtime.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
+// piehip.cpp -- C ABI (include/piehip.h) over the gfx950 kernels: the context, keys and database of a handle, its query inputs,
+// and the launch schedule of BatchedFHEHIPPIE::run() (reference BatchedFHEHIPPIE.cpp:88-129) on the handle's queues.
+// The other entry points live in piehip_host.cpp / _ops.cpp / _fhepie.cpp / _client.cpp / _rccl.cpp (piehip_ctx.hpp lists them).
+#include "piehip_ctx.hpp"
 
 #include <random>
-#include <algorithm>
-#include <map>
-#include <memory>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "kernels.hpp"
-#include "params.hpp"
 
 using namespace piehip;
 
 static thread_local std::string g_err;
-static int fail(int code, const std::string &msg)
+namespace piehip {
+int fail(int code, const std::string &msg)
 {
     g_err = msg;
     return code;
 }
-#define HIPCHK(expr)                                                                                   \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess)                                                                          \
-            return fail(PIEHIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
-    } while (0)
-struct piehip_ctx;
-static void join_pending(piehip_ctx *h);
-static void mark_dirty(piehip_ctx *h);
+}  // namespace piehip
 static void free_workspace(piehip_ctx *h);
-// every entry point except piehip_run first orders the handle's stream behind the bin-layer queues of earlier runs
-#define NEED_RO(h)                                              \
-    do {                                                        \
-        if (!(h)) return fail(PIEHIP_EINVAL, "null handle");    \
-        join_pending(h);                                        \
-    } while (0)
-// ... and, unless it only reads (NEED_RO), may queue work on the handle's stream that the next run has to wait for
-#define NEED(h)                                                 \
-    do {                                                        \
-        NEED_RO(h);                                             \
-        mark_dirty(h);                                          \
-    } while (0)
 
-namespace {
+namespace piehip {
 
-struct ProfRec {
-    hipEvent_t a, b;
-    int k;
-    double bytes;
-};
-
-// scratch of one batched EvalMult(ct,ct) over nb ciphertext pairs
-struct MulWs {
-    u32 nb = 0;
-    u64 *eqp = nullptr;  // [nb][4][M][N]
-    u64 *dqp = nullptr;  // [nb][3][M][N]
-    u64 *d01 = nullptr;  // [nb][2][L][N]
-    u64 *d2c = nullptr;  // [nb][L][N]
-    u64 *dig = nullptr;  // [nb][L][L][N]
-};
-
-}  // namespace
-
-struct piehip_ctx {
-    HostParams hp;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    std::vector<hipStream_t> side_streams;        // extra queues of run(): one group of bin layers each (see piehip_run)
-    std::vector<hipEvent_t> ev_join;
-    hipEvent_t ev_fork = nullptr;
-    u32 run_streams = 0;                          // piehip_set_run_streams: 0 = all queues
-    bool inputs_dirty = true;                     // inputs / keys / database changed on the handle's stream since the last run()
-    hipEvent_t wait_before_results = nullptr;     // set while run() enqueues a group: its result-writing kernel waits for this
-    bool pending_join = false;                    // run() left work on the bin-layer queues that the handle's stream has not waited for
-    // piehip_set_graph: run() as one captured hipGraph per (inputs, result buffer, queue count), replayed on the handle's stream
-    bool use_graph = false;
-    hipGraphExec_t gexec = nullptr;
-    const void *g_idx = nullptr, *g_minus = nullptr, *g_res = nullptr;
-    u32 g_ng = 0;
-    // piehip_run_host: copy queue, one "row landed" event per inner hash function, pinned staging owned by the handle
-    hipStream_t copy_stream = nullptr;
-    std::vector<hipEvent_t> ev_h2d;               // [K]: index-matrix row h (and, for h = 0, the minus element) is in HBM
-    hipEvent_t ev_copy_gate = nullptr, ev_minus_h2d = nullptr;
-    bool stage_open = false, staged_minus = false;  // piehip_stage_*: a query's uploads have begun; which pieces are on their way
-    std::vector<bool> staged_rows;
-    const hipEvent_t *row_events = nullptr;       // set while piehip_run_host enqueues: stage A of row h waits for row_events[h]
-    u64 *pin_idx = nullptr, *pin_minus = nullptr, *pin_res = nullptr;
-    size_t pin_idx_words = 0, pin_res_words = 0;
-    DevConsts *d_dc = nullptr;
-    u64 *d_tables = nullptr;  // [(M+1)][4][N]
-    u64 *d_twp = nullptr;     // [(M+1)][2][N][2] interleaved {w, w_shoup}
-    u64 *d_twc = nullptr;     // pass-C kernel-order copy of the same pairs
-    u64 *d_twc_fold = nullptr;  // ... for the folded configuration (two half-size slices per limb)
-    bool fold_on = false;     // outermost NTT stage folded into the coefficient-wise kernels (N >= 2^14)
-    u32 *d_inv_pos = nullptr; // EVALUATION position -> slot
-    u32 *d_sigma_inv = nullptr;  // lane-order position -> standard position (identity for small rings)
-    u32 sigma_T = 0;             // threads per slice of the transform that defines the lane order
-    u32 sigma_kp = 16;           // ... and coefficient pairs per thread (16: kernels_ntt_fast.hip, 8: ntt16_kernel.h)
-    u64 *d_twk16 = nullptr;      // ntt16_kernel.h tables (ring 2^13 as one slice per limb; rings 2^14, 2^15 as two folded slices)
-    bool small_moduli = false;   // all Q and P moduli in (2^59, 2^60): v_mad_u64_u32 column accumulators, one-word Barrett
-    bool sigma_on = false;       // the register-blocked NTT (and hence the lane order) applies to this context
-    u64 *d_evk_sigma = nullptr, *d_masks_sigma = nullptr;  // lane-ordered copies of key and masks
-    u64 *d_hash_tbl = nullptr;   // [k][e][K][b][E] of the last piehip_build_db
-    size_t hash_tbl_words = 0;
-    // scratch of the offline phase (hashing, packing, encoding), kept between calls: piehip_reserve sizes it up front so that
-    // the timed offline phase allocates nothing (hipMalloc / hipFree cost milliseconds and synchronise the device)
-    u64 *arena = nullptr;
-    size_t arena_words = 0, arena_used = 0;
-    u32 hk = 0, he = 0, hb = 0;  // table dimensions ([k][e][K][hb][E]; hb = all bin layers, of which this handle keeps b)
-    NttPlan plan;
-    // keys / database / inputs
-    bool db_borrowed = false;  // piehip_attach_database: d_evk*, d_db, d_masks* belong to another handle (never freed or written here)
-    piehip_ctx *db_owner = nullptr;  // ... that handle
-    u32 db_borrowers = 0;            // handles that borrow from this one: its buffers may not move while > 0
-    u64 *d_evk = nullptr;
-    u32 K = 0, b = 0, E = 0;
-    u64 *d_db = nullptr, *d_masks = nullptr;
-    u64 *d_idx_own = nullptr, *d_minus_own = nullptr;
-    const u64 *d_idx = nullptr, *d_minus = nullptr;
-    // query batch (piehip_set_query_batch): run() evaluates nq queries against the database at once; query 0 is d_idx / d_minus
-    // above, queries 1 .. nq - 1 are bq_*[q].  Workspace and results hold nq rows per bin layer: [b][nq][..].
-    u32 nq = 1;
-    u32 mask_div = 1;  // set while run() enqueues a batch: ciphertext row r of the product chain takes mask r / mask_div
-    const u64 *bq_idx[STAGE_A_MAX_QUERIES] = {}, *bq_minus[STAGE_A_MAX_QUERIES] = {};
-    u64 *bq_idx_own[STAGE_A_MAX_QUERIES] = {}, *bq_minus_own[STAGE_A_MAX_QUERIES] = {};
-    // run() workspace
-    u64 *d_acc = nullptr;   // [b][K][2][L][N]
-    u64 *d_prod = nullptr;  // [b][2][L][N]  (K > 2 only)
-    u64 *d_out = nullptr;   // [b][2][L][N]
-    MulWs ws;
-    // rotation-based PIE (FHEHIPPIE): rotation keys by index, EVALUATION index maps, packed sub-tables
-    std::map<int32_t, u64 *> rotkeys;   // [L][2][L][N] each
-    std::map<int32_t, u32 *> rotmaps;   // [N] each
-    u32 fp_npie = 0, fp_K = 0, fp_b = 0, fp_E = 0;
-    u64 *fp_pt = nullptr;     // [npie][K][b][L][N]
-    u64 *fp_mask = nullptr;   // [npie][K][L][N]
-    u64 *fp_e0 = nullptr;     // [L][N]: plaintext with slot 0 = 1 (EvalMerge's mask)
-    u64 *fp_idx = nullptr;    // [npie][K][2][L][N]
-    u64 *fp_out = nullptr;    // [npie][K][2][L][N]
-    u64 *fp_negkeys = nullptr;  // [b][L][2][L][N]: key of rotation -r at position r (position 0 unused)
-    u32 *fp_negmaps = nullptr;  // [b][N]
-    // profiling
-    bool profiling = false;
-    std::vector<ProfRec> recs;
-    std::vector<hipEvent_t> pool;
-    size_t pool_used = 0;
-
-    size_t LN() const { return (size_t)hp.L * hp.N; }
-};
-
-static void join_pending(piehip_ctx *h)
+void join_pending(piehip_ctx *h)
 {
     if (!h->pending_join) return;
     for (size_t g = 0; g < h->ev_join.size(); g++) (void)hipStreamWaitEvent(h->stream, h->ev_join[g], 0);
     h->pending_join = false;
 }
 
-static void mark_dirty(piehip_ctx *h) { h->inputs_dirty = true; }
+void mark_dirty(piehip_ctx *h) { h->inputs_dirty = true; }
 
-static void drop_graph(piehip_ctx *h)
+void drop_graph(piehip_ctx *h)
 {
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     h->gexec = nullptr;
 }
 
+}  // namespace piehip
 static const char *KNAMES[PIEHIP_NKERNELS] = {"stage_a_mac", "ntt_fwd", "ntt_inv",  "expand",   "tensor",    "scale_round",
                                               "digits",      "relin",   "mask_mul", "encode",   "automorph", "other"};
+namespace piehip {
 
 // ---- profiling helpers -------------------------------------------------------------------------
-static hipEvent_t prof_event(piehip_ctx *h)
+hipEvent_t prof_event(piehip_ctx *h)
 {
     if (h->pool_used == h->pool.size()) {
         hipEvent_t e;
@@ -186,32 +49,8 @@ static hipEvent_t prof_event(piehip_ctx *h)
     }
     return h->pool[h->pool_used++];
 }
-struct ProfScope {
-    piehip_ctx *h;
-    ProfRec r;
-    bool on;
-    ProfScope(piehip_ctx *h_, int k, double bytes) : h(h_), on(h_->profiling)
-    {
-        if (!on) return;
-        r.k = k;
-        r.bytes = bytes;
-        r.a = prof_event(h);
-        r.b = prof_event(h);
-        if (!r.a || !r.b) {
-            on = false;
-            return;
-        }
-        (void)hipEventRecord(r.a, h->stream);
-    }
-    ~ProfScope()
-    {
-        if (!on) return;
-        (void)hipEventRecord(r.b, h->stream);
-        h->recs.push_back(r);
-    }
-};
 
-static int dev_alloc(u64 **p, size_t words)
+int dev_alloc(u64 **p, size_t words)
 {
     *p = nullptr;
     if (!words) return PIEHIP_OK;
@@ -219,45 +58,13 @@ static int dev_alloc(u64 **p, size_t words)
     if (e != hipSuccess) return fail(PIEHIP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
     return PIEHIP_OK;
 }
-static void dev_free(u64 **p)
+void dev_free(u64 **p)
 {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
 }
 
-namespace {
-struct Tmp {  // RAII device scratch: carved from the handle's arena while it has room, hipMalloc otherwise
-    piehip_ctx *h = nullptr;
-    size_t mark = 0;
-    std::vector<u64 *> ptrs;
-    Tmp() {}
-    explicit Tmp(piehip_ctx *h_) : h(h_), mark(h_->arena_used) {}
-    ~Tmp()
-    {
-        for (u64 *p : ptrs) (void)hipFree(p);
-        if (h) h->arena_used = mark;
-    }
-    u64 *get(size_t words)
-    {
-        if (!words) words = 1;
-        const size_t w32 = (words + 31) & ~(size_t)31;  // 256-byte granules
-        if (h && h->arena && h->arena_used + w32 <= h->arena_words) {
-            u64 *p = h->arena + h->arena_used;
-            h->arena_used += w32;
-            return p;
-        }
-        u64 *p = nullptr;
-        if (hipMalloc((void **)&p, words * sizeof(u64)) != hipSuccess) return nullptr;
-        ptrs.push_back(p);
-        return p;
-    }
-};
-}  // namespace
-#define TMPGET(var, words)                                          \
-    u64 *var = tmp.get(words);                                      \
-    if (!var) return fail(PIEHIP_ENOMEM, "hipMalloc failed (scratch)")
-
-static int ws_alloc(piehip_ctx *h, MulWs &w, u32 nb)
+int ws_alloc(piehip_ctx *h, MulWs &w, u32 nb)
 {
     const size_t N = h->hp.N, L = h->hp.L, M = h->hp.M;
     w.nb = nb;
@@ -269,7 +76,7 @@ static int ws_alloc(piehip_ctx *h, MulWs &w, u32 nb)
     if ((rc = dev_alloc(&w.dig, (size_t)nb * L * L * N))) return rc;
     return PIEHIP_OK;
 }
-static void ws_free(MulWs &w)
+void ws_free(MulWs &w)
 {
     dev_free(&w.eqp);
     dev_free(&w.dqp);
@@ -282,8 +89,7 @@ static void ws_free(MulWs &w)
 // ---- schedule pieces ----------------------------------------------------------------------------
 // sigma: lane order on the EVALUATION side; fold: outer stage applied by the neighbouring kernels (both only
 // take effect when the context supports them; callers pass the same flags to those neighbours)
-static void ntt(piehip_ctx *h, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inv, bool sigma = false, bool fold = false,
-                const NttExtra *ex = nullptr)
+void ntt(piehip_ctx *h, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool inv, bool sigma, bool fold, const NttExtra *ex)
 {
     ProfScope ps(h, inv ? PIEHIP_K_NTT_INV : PIEHIP_K_NTT_FWD, 16.0 * h->hp.N * nlimbs);
     launch_ntt(h->plan, data, nlimbs, mod_base, mod_count, inv, h->stream, sigma && h->sigma_on, fold && h->fold_on, ex);
@@ -291,14 +97,13 @@ static void ntt(piehip_ctx *h, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_coun
 // The X operand of a ciphertext multiplication is available in EVALUATION format before its inverse transform; when
 // the register-blocked kernel runs that transform it also drops a lane-ordered copy into the Q limbs of the QP operand
 // array, and the forward transform over QP skips those limbs (8 of 36 per bin layer at L = 4).
-static bool xq_reuse(const piehip_ctx *h) { return h->sigma_on && ntt_supports_extra(h->plan, h->fold_on); }
+bool xq_reuse(const piehip_ctx *h) { return h->sigma_on && ntt_supports_extra(h->plan, h->fold_on); }
 
 // BV key switch of the COEFFICIENT-format polynomials at w.d2c with `key`, added to the EVALUATION
 // ciphertexts at w.d01, optionally multiplied by mask plaintexts: out[nb][2][L][N]
 // sigma: w.d01 and the digits are in lane order, key/mask are lane-ordered copies, out is written in standard order
-static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, const u64 *mask, u64 *out, bool sigma = false,
-                              bool fold = false, size_t key_stride = 0, u32 key_group = 1, bool out_is_result = false,
-                              bool digits_ready = false)
+void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, const u64 *mask, u64 *out, bool sigma, bool fold,
+                       size_t key_stride, u32 key_group, bool out_is_result, bool digits_ready)
 {
     const u32 N = h->hp.N, L = h->hp.L;
     const size_t LN = h->LN();
@@ -332,8 +137,8 @@ static void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, c
 // ntt(.., inverse, sigma = false, fold = true): with folding on, their outermost inverse stage is applied here),
 // X polynomial (o,c) at x + o*sx + c*LN, Y likewise.  relin: out[nb][2][L][N] (times mask if given);
 // otherwise out[nb][3][L][N] holds the EVALUATION-format tensor result.
-static void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const u64 *y, size_t sy, u32 nb, bool relin,
-                        const u64 *mask, u64 *out, bool xq_ready = false, bool out_is_result = false)
+void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const u64 *y, size_t sy, u32 nb, bool relin,
+                 const u64 *mask, u64 *out, bool xq_ready, bool out_is_result)
 {
     const u32 N = h->hp.N, L = h->hp.L, M = h->hp.M;
     const size_t LN = h->LN();
@@ -385,6 +190,8 @@ static void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const 
         ntt(h, out, nb * 3 * L, 0, L, false, false, true);
     }
 }
+
+}  // namespace piehip
 
 // =================================================================================================
 extern "C" {
@@ -831,7 +638,9 @@ static size_t build_db_scratch_words(const piehip_ctx *h, size_t n, u32 k, u32 e
 }
 
 // device-side MakePackedPlaintext of npt slot vectors (already on the device) into out[npt][L][N]
-static int encode_on_device(piehip_ctx *h, const int64_t *d_slots, u32 npt, u32 B, u64 *d_out)
+}  // extern "C"
+namespace piehip {
+int encode_on_device(piehip_ctx *h, const int64_t *d_slots, u32 npt, u32 B, u64 *d_out)
 {
     const u32 N = h->hp.N, L = h->hp.L, M = h->hp.M;
     // chunk so the mod-t scratch stays small
@@ -850,6 +659,8 @@ static int encode_on_device(piehip_ctx *h, const int64_t *d_slots, u32 npt, u32 
     if (e != hipSuccess) return fail(PIEHIP_EHIP, std::string("encode: ") + hipGetErrorString(e));
     return PIEHIP_OK;
 }
+}  // namespace piehip
+extern "C" {
 
 int piehip_load_db_slots(piehip_handle h, uint32_t K, uint32_t b, uint32_t E, uint32_t B, const int64_t *slots,
                          const int64_t *mask_slots)
@@ -1219,15 +1030,21 @@ int piehip_set_minus_q(piehip_handle h, uint32_t q, const uint64_t *minus)
 // every launch is bound by its own latency, a second queue only interleaves two latency-bound chains on the same CUs, and one
 // queue is faster (measured at the C3 ring: 2 layers 115 vs 146 us, 5 layers of the E = 40 row 217 vs 239 us, 7 layers even).
 static const u32 MAX_RUN_QUEUES = 2;  // 3 is equal within noise, 4 and more collapse
-static u32 run_queue_count(const piehip_ctx *h)
+}  // extern "C"
+namespace piehip {
+u32 run_queue_count(const piehip_ctx *h)
 {
     const u32 want = h->run_streams ? h->run_streams : (h->b >= 8 ? 2u : 1u);
     return std::min(want, std::min(MAX_RUN_QUEUES, h->b));
 }
+}  // namespace piehip
+extern "C" {
 // The queues are created when a run first needs them: a handle that runs on one queue (a query slot, a rank's small share)
 // then owns one stream, not three -- the runtime multiplexes streams onto a few hardware queues, and streams that share one
 // serialise against each other.
-static int ensure_run_queues(piehip_ctx *h, u32 ng)
+}  // extern "C"
+namespace piehip {
+int ensure_run_queues(piehip_ctx *h, u32 ng)
 {
     while (h->side_streams.size() < ng) {
         hipStream_t s = nullptr;
@@ -1239,10 +1056,14 @@ static int ensure_run_queues(piehip_ctx *h, u32 ng)
     }
     return PIEHIP_OK;
 }
+}  // namespace piehip
+extern "C" {
 
 // bin layers of queue group g of ng.  Two groups take 4/7 and 3/7 of the layers: measured 3.5 % faster than equal halves at
 // b = 14 (8 + 6: the ragged transform launches of the two queues fit the workgroup slots better than 7 + 7).
-static u32 run_group_size(u32 b, u32 ng, u32 g)
+}  // extern "C"
+namespace piehip {
+u32 run_group_size(u32 b, u32 ng, u32 g)
 {
     if (ng == 2) {
         const u32 first = (4 * b + 3) / 7;
@@ -1250,6 +1071,8 @@ static u32 run_group_size(u32 b, u32 ng, u32 g)
     }
     return b / ng + (g < b % ng ? 1 : 0);
 }
+}  // namespace piehip
+extern "C" {
 
 // Bin layers [b0, b0 + nb) of run() on the handle's current stream: stage A, then the product chain.
 static void enqueue_run_bins(piehip_ctx *h, u32 b0, u32 nb, u64 *results)
@@ -1443,172 +1266,6 @@ int piehip_run(piehip_handle h)
     return piehip_run_into(h, h->d_out);
 }
 
-static int host_path_setup(piehip_ctx *h)
-{
-    if (h->nq > 1) return fail(PIEHIP_ESTATE, "the host-buffer path takes one query per run() (piehip_set_query_batch(h, 1))");
-    if (!h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-    if (!h->ev_copy_gate) HIPCHK(hipEventCreateWithFlags(&h->ev_copy_gate, hipEventDisableTiming));
-    if (!h->ev_minus_h2d) HIPCHK(hipEventCreateWithFlags(&h->ev_minus_h2d, hipEventDisableTiming));
-    while (h->ev_h2d.size() < h->K) {
-        hipEvent_t e = nullptr;
-        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        h->ev_h2d.push_back(e);
-    }
-    return PIEHIP_OK;
-}
-
-int piehip_host_buffers(piehip_handle h, uint64_t **idx, uint64_t **minus, uint64_t **results)
-{
-    NEED_RO(h);
-    if (!h->K) return fail(PIEHIP_ESTATE, "load the database first (the buffer sizes depend on K, E and b)");
-    HIPCHK(hipSetDevice(h->device));
-    const size_t iw = (size_t)h->K * h->E * 2 * h->LN(), rw = (size_t)h->b * 2 * h->LN();
-    if (h->pin_idx && h->pin_idx_words != iw) {
-        (void)hipHostFree(h->pin_idx);
-        h->pin_idx = nullptr;
-    }
-    if (h->pin_res && h->pin_res_words != rw) {
-        (void)hipHostFree(h->pin_res);
-        h->pin_res = nullptr;
-    }
-    if (!h->pin_idx) HIPCHK(hipHostMalloc((void **)&h->pin_idx, iw * sizeof(u64), hipHostMallocDefault));
-    if (!h->pin_minus) HIPCHK(hipHostMalloc((void **)&h->pin_minus, 2 * h->LN() * sizeof(u64), hipHostMallocDefault));
-    if (!h->pin_res) HIPCHK(hipHostMalloc((void **)&h->pin_res, rw * sizeof(u64), hipHostMallocDefault));
-    h->pin_idx_words = iw;
-    h->pin_res_words = rw;
-    // whoever asks for the staging arrays is about to run queries from host memory: create the copy queue, its events and the
-    // run queues now (the offline phase), not inside the first timed query
-    int rc = host_path_setup(h);
-    if (rc) return rc;
-    const u32 ng = run_queue_count(h);
-    if (ng > 1 && (rc = ensure_run_queues(h, ng))) return rc;
-    if (idx) *idx = h->pin_idx;
-    if (minus) *minus = h->pin_minus;
-    if (results) *results = h->pin_res;
-    return PIEHIP_OK;
-}
-
-// One query's uploads, piece by piece (piehip_stage_*): the copy queue is gated once behind everything queued so far -- the uploads
-// may not overtake a run that still reads the input buffers -- and every piece is one asynchronous copy from host memory.
-static int stage_begin(piehip_ctx *h)
-{
-    if (!h->K || !h->d_db) return fail(PIEHIP_ESTATE, "run: database not loaded");
-    HIPCHK(hipSetDevice(h->device));
-    if (h->stage_open) return PIEHIP_OK;
-    int rc = host_path_setup(h);
-    if (rc) return rc;
-    const size_t LN = h->LN(), row = (size_t)h->E * 2 * LN;
-    if (!h->d_idx_own && (rc = dev_alloc(&h->d_idx_own, (size_t)h->K * row))) return rc;
-    if (!h->d_minus_own && (rc = dev_alloc(&h->d_minus_own, 2 * LN))) return rc;
-    join_pending(h);
-    HIPCHK(hipEventRecord(h->ev_copy_gate, h->stream));
-    HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_copy_gate, 0));
-    h->stage_open = true;
-    h->staged_minus = false;
-    h->staged_rows.assign(h->K, false);
-    return PIEHIP_OK;
-}
-
-int piehip_stage_minus(piehip_handle h, const uint64_t *minus)
-{
-    if (!h) return fail(PIEHIP_EINVAL, "null handle");
-    if (!minus) return fail(PIEHIP_EINVAL, "null input");
-    int rc = stage_begin(h);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(h->d_minus_own, minus, 2 * h->LN() * sizeof(u64), hipMemcpyHostToDevice, h->copy_stream));
-    HIPCHK(hipEventRecord(h->ev_minus_h2d, h->copy_stream));
-    h->staged_minus = true;
-    return PIEHIP_OK;
-}
-
-int piehip_stage_index_row(piehip_handle h, uint32_t row, const uint64_t *row_data)
-{
-    if (!h) return fail(PIEHIP_EINVAL, "null handle");
-    if (!row_data) return fail(PIEHIP_EINVAL, "null input");
-    int rc = stage_begin(h);
-    if (rc) return rc;
-    if (row >= h->K) return fail(PIEHIP_EINVAL, "stage_index_row: the index matrix has one row per inner hash function");
-    const size_t words = (size_t)h->E * 2 * h->LN();
-    HIPCHK(hipMemcpyAsync(h->d_idx_own + (size_t)row * words, row_data, words * sizeof(u64), hipMemcpyHostToDevice, h->copy_stream));
-    HIPCHK(hipEventRecord(h->ev_h2d[row], h->copy_stream));
-    h->staged_rows[row] = true;
-    return PIEHIP_OK;
-}
-
-int piehip_run_staged(piehip_handle h, uint64_t *results)
-{
-    if (!h) return fail(PIEHIP_EINVAL, "null handle");
-    if (!h->K || !h->d_db) return fail(PIEHIP_ESTATE, "run: database not loaded");
-    if (!h->d_evk && h->K > 1) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
-    if (!h->stage_open || !h->staged_minus) return fail(PIEHIP_ESTATE, "run_staged: minus element not staged");
-    for (u32 hf = 0; hf < h->K; hf++)
-        if (!h->staged_rows[hf]) return fail(PIEHIP_ESTATE, "run_staged: index matrix row not staged");
-    HIPCHK(hipSetDevice(h->device));
-    const size_t LN = h->LN();
-    h->stage_open = false;
-    h->d_idx = h->d_idx_own;
-    h->d_minus = h->d_minus_own;
-    // the minus element enters at the end of every stage A launch: the handle's stream (and, through the fork, every queue)
-    // waits for it; row h of the index matrix is waited for by stage A of row h only
-    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_minus_h2d, 0));
-    mark_dirty(h);
-    h->row_events = h->ev_h2d.data();
-    int rc = piehip_run_into(h, h->d_out);
-    h->row_events = nullptr;
-    if (rc) return rc;
-    if (results) {
-        // every queue group's slice of the result list leaves as soon as that group is done
-        if (h->pending_join) {
-            const u32 ng = run_queue_count(h);
-            u32 b0 = 0;
-            for (u32 g = 0; g < ng; g++) {
-                const u32 nb = run_group_size(h->b, ng, g);
-                HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_join[g], 0));
-                HIPCHK(hipMemcpyAsync(results + (size_t)b0 * 2 * LN, h->d_out + (size_t)b0 * 2 * LN, (size_t)nb * 2 * LN * sizeof(u64),
-                                      hipMemcpyDeviceToHost, h->copy_stream));
-                b0 += nb;
-            }
-        } else {
-            HIPCHK(hipEventRecord(h->ev_copy_gate, h->stream));
-            HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_copy_gate, 0));
-            HIPCHK(hipMemcpyAsync(results, h->d_out, (size_t)h->b * 2 * LN * sizeof(u64), hipMemcpyDeviceToHost, h->copy_stream));
-        }
-    }
-    return PIEHIP_OK;
-}
-
-int piehip_run_host_async(piehip_handle h, const uint64_t *idx, const uint64_t *minus, uint64_t *results)
-{
-    if (!h) return fail(PIEHIP_EINVAL, "null handle");
-    if (!idx || !minus) return fail(PIEHIP_EINVAL, "null input");
-    if (h->K && !h->d_evk && h->K > 1) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
-    h->stage_open = false;  // a query of its own: pieces staged earlier and never run are dropped
-    int rc = piehip_stage_minus(h, minus);
-    const size_t row = (size_t)h->E * 2 * h->LN();
-    for (u32 hf = 0; hf < h->K && !rc; hf++) rc = piehip_stage_index_row(h, hf, idx + (size_t)hf * row);
-    if (rc) {
-        h->stage_open = false;
-        return rc;
-    }
-    return piehip_run_staged(h, results);
-}
-
-int piehip_run_host_wait(piehip_handle h)
-{
-    if (!h) return fail(PIEHIP_EINVAL, "null handle");
-    HIPCHK(hipSetDevice(h->device));
-    if (h->copy_stream) HIPCHK(hipStreamSynchronize(h->copy_stream));
-    join_pending(h);
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return PIEHIP_OK;
-}
-
-int piehip_run_host(piehip_handle h, const uint64_t *idx, const uint64_t *minus, uint64_t *results)
-{
-    const int rc = piehip_run_host_async(h, idx, minus, results);
-    return rc ? rc : piehip_run_host_wait(h);
-}
-
 int piehip_join(piehip_handle h)
 {
     NEED_RO(h);
@@ -1662,692 +1319,6 @@ int piehip_copy_results_device(piehip_handle h, void *d_dst)
     if (!d_dst) return fail(PIEHIP_EINVAL, "null destination");
     if (!h->d_out) return fail(PIEHIP_ESTATE, "no results");
     HIPCHK(hipMemcpyAsync(d_dst, h->d_out, sizeof(u64) * (size_t)h->b * h->nq * 2 * h->LN(), hipMemcpyDeviceToDevice, h->stream));
-    return PIEHIP_OK;
-}
-
-// ---- kernel-level entry points (tests) -------------------------------------------------------------
-
-int piehip_ntt(piehip_handle h, uint64_t *limbs, uint32_t nlimbs, uint32_t mod_base, uint32_t mod_count, int inverse)
-{
-    NEED(h);
-    if (!limbs || !mod_count || mod_base + mod_count > h->hp.M + 1) return fail(PIEHIP_EINVAL, "bad modulus range");
-    HIPCHK(hipSetDevice(h->device));
-    Tmp tmp;
-    const size_t words = (size_t)nlimbs * h->hp.N;
-    TMPGET(d, words);
-    HIPCHK(hipMemcpy(d, limbs, words * sizeof(u64), hipMemcpyHostToDevice));
-    ntt(h, d, nlimbs, mod_base, mod_count, inverse != 0);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(limbs, d, words * sizeof(u64), hipMemcpyDeviceToHost));
-    return PIEHIP_OK;
-}
-
-static int ew_common(piehip_handle h, const uint64_t *x, const uint64_t *y, uint64_t *out, bool mul)
-{
-    NEED(h);
-    if (!x || !y || !out) return fail(PIEHIP_EINVAL, "null operand");
-    HIPCHK(hipSetDevice(h->device));
-    Tmp tmp;
-    const size_t LN = h->LN();
-    TMPGET(dx, 2 * LN);
-    TMPGET(dy, 2 * LN);
-    TMPGET(dz, 2 * LN);
-    HIPCHK(hipMemcpy(dx, x, 2 * LN * sizeof(u64), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dy, y, (mul ? 1 : 2) * LN * sizeof(u64), hipMemcpyHostToDevice));
-    if (mul)
-        launch_ct_mul_plain(h->d_dc, h->hp.N, h->hp.L, dx, dy, 0, dz, 1, h->stream);
-    else
-        launch_ct_add(h->d_dc, h->hp.N, h->hp.L, dx, dy, dz, 1, h->stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(out, dz, 2 * LN * sizeof(u64), hipMemcpyDeviceToHost));
-    return PIEHIP_OK;
-}
-int piehip_eval_add(piehip_handle h, const uint64_t *x, const uint64_t *y, uint64_t *out) { return ew_common(h, x, y, out, false); }
-int piehip_eval_mult_plain(piehip_handle h, const uint64_t *x, const uint64_t *pt, uint64_t *out)
-{
-    return ew_common(h, x, pt, out, true);
-}
-
-int piehip_eval_mult(piehip_handle h, const uint64_t *x, const uint64_t *y, uint32_t nct, int relin, uint64_t *out)
-{
-    NEED(h);
-    if (!x || !y || !out || !nct) return fail(PIEHIP_EINVAL, "null operand");
-    if (relin && !h->d_evk) return fail(PIEHIP_ESTATE, "relinearisation key not loaded");
-    HIPCHK(hipSetDevice(h->device));
-    Tmp tmp;
-    const size_t LN = h->LN();
-    const u32 L = h->hp.L;
-    TMPGET(dxy, (size_t)nct * 4 * LN);  // [nct][x,y][2][L][N]
-    TMPGET(dout, (size_t)nct * 3 * LN);
-    for (u32 i = 0; i < nct; i++) {
-        HIPCHK(hipMemcpy(dxy + (size_t)i * 4 * LN, x + (size_t)i * 2 * LN, 2 * LN * sizeof(u64), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(dxy + (size_t)i * 4 * LN + 2 * LN, y + (size_t)i * 2 * LN, 2 * LN * sizeof(u64), hipMemcpyHostToDevice));
-    }
-    MulWs w;
-    int rc = ws_alloc(h, w, nct);
-    if (rc) {
-        ws_free(w);
-        return rc;
-    }
-    const bool xq = xq_reuse(h);
-    NttExtra ex;  // operand layout [nct][x, y][2][L]: x is "operand 0" of every pair
-    ex.copy_out = w.eqp;
-    ex.copy_K = 2;
-    ex.copy_L = L;
-    ex.copy_M = h->hp.M;
-    ntt(h, dxy, nct * 4 * L, 0, L, true, false, true, xq ? &ex : nullptr);
-    enqueue_mul(h, w, dxy, 4 * LN, dxy + 2 * LN, 4 * LN, nct, relin != 0, nullptr, dout, xq);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    ws_free(w);
-    if (e != hipSuccess) return fail(PIEHIP_EHIP, std::string("eval_mult: ") + hipGetErrorString(e));
-    HIPCHK(hipMemcpy(out, dout, (size_t)nct * (relin ? 2 : 3) * LN * sizeof(u64), hipMemcpyDeviceToHost));
-    return PIEHIP_OK;
-}
-
-int piehip_eval_automorph(piehip_handle h, const uint64_t *x, uint32_t g, const uint64_t *rk, uint64_t *out)
-{
-    NEED(h);
-    if (!x || !rk || !out) return fail(PIEHIP_EINVAL, "null operand");
-    if (!(g & 1) || g >= 2 * h->hp.N) return fail(PIEHIP_EINVAL, "automorphism index must be odd and < 2N");
-    HIPCHK(hipSetDevice(h->device));
-    Tmp tmp;
-    const size_t LN = h->LN();
-    const u32 N = h->hp.N, L = h->hp.L;
-    TMPGET(dx, 2 * LN);
-    TMPGET(dk, (size_t)L * 2 * LN);
-    TMPGET(dperm, 2 * LN);
-    TMPGET(dout, 2 * LN);
-    TMPGET(dmapw, (N + 1) / 2 + 1);
-    u32 *dmap = (u32 *)dmapw;
-    std::vector<u32> map = h->hp.automorph_map(g);
-    HIPCHK(hipMemcpy(dx, x, 2 * LN * sizeof(u64), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dk, rk, (size_t)L * 2 * LN * sizeof(u64), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dmap, map.data(), sizeof(u32) * N, hipMemcpyHostToDevice));
-    MulWs w;
-    int rc = ws_alloc(h, w, 1);
-    if (rc) {
-        ws_free(w);
-        return rc;
-    }
-    {
-        ProfScope ps(h, PIEHIP_K_AUTOMORPH, 16.0 * N * 2 * L);
-        launch_permute(N, dx, dmap, dperm, 2 * L, h->stream);
-    }
-    // (sigma(c0), 0) stays in EVALUATION format; sigma(c1) goes through the key switch
-    (void)hipMemcpyAsync(w.d01, dperm, LN * sizeof(u64), hipMemcpyDeviceToDevice, h->stream);
-    (void)hipMemsetAsync(w.d01 + LN, 0, LN * sizeof(u64), h->stream);
-    (void)hipMemcpyAsync(w.d2c, dperm + LN, LN * sizeof(u64), hipMemcpyDeviceToDevice, h->stream);
-    ntt(h, w.d2c, L, 0, L, true);
-    enqueue_keyswitch(h, w, 1, dk, nullptr, dout);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    ws_free(w);
-    if (e != hipSuccess) return fail(PIEHIP_EHIP, std::string("eval_automorph: ") + hipGetErrorString(e));
-    HIPCHK(hipMemcpy(out, dout, 2 * LN * sizeof(u64), hipMemcpyDeviceToHost));
-    return PIEHIP_OK;
-}
-
-int piehip_encode(piehip_handle h, const int64_t *slots, uint32_t npt, uint32_t B, uint64_t *out)
-{
-    NEED(h);
-    if (!slots || !out || !npt) return fail(PIEHIP_EINVAL, "null operand");
-    if (B > h->hp.N) return fail(PIEHIP_EINVAL, "batch size exceeds the ring dimension");
-    const u64 t = h->hp.t;
-    for (size_t i = 0; i < (size_t)npt * B; i++) {
-        const int64_t v = slots[i];
-        if ((u64)(v < 0 ? -v : v) >= t) return fail(PIEHIP_EINVAL, "slot value out of range for the plaintext modulus");
-    }
-    HIPCHK(hipSetDevice(h->device));
-    Tmp tmp;
-    TMPGET(dsw, (size_t)npt * B);
-    TMPGET(dout, (size_t)npt * h->LN());
-    HIPCHK(hipMemcpy(dsw, slots, sizeof(int64_t) * (size_t)npt * B, hipMemcpyHostToDevice));
-    int rc = encode_on_device(h, (const int64_t *)dsw, npt, B, dout);
-    if (rc) return rc;
-    HIPCHK(hipMemcpy(out, dout, sizeof(u64) * (size_t)npt * h->LN(), hipMemcpyDeviceToHost));
-    return PIEHIP_OK;
-}
-
-int piehip_base_convert(piehip_handle h, int which, const uint64_t *in, uint32_t npoly, uint64_t *out)
-{
-    NEED(h);
-    if (!in || !out || !npoly || which < 0 || which > 2) return fail(PIEHIP_EINVAL, "bad argument");
-    if (which == 2 && npoly % 3) return fail(PIEHIP_EINVAL, "scale-and-round takes polynomials in triples");
-    if (which != 2 && npoly % 2) return fail(PIEHIP_EINVAL, "extension takes polynomials in pairs");
-    HIPCHK(hipSetDevice(h->device));
-    Tmp tmp;
-    const u32 N = h->hp.N, L = h->hp.L, M = h->hp.M;
-    const size_t LN = h->LN(), MN = (size_t)M * N;
-    const size_t win = (size_t)npoly * (which == 2 ? MN : LN), wout = (size_t)npoly * (which == 2 ? LN : MN);
-    TMPGET(din, win);
-    TMPGET(dout, wout);
-    set_small_moduli(h->small_moduli);
-    HIPCHK(hipMemcpy(din, in, win * sizeof(u64), hipMemcpyHostToDevice));
-    if (which == 0)
-        launch_expand_q_to_qp(h->d_dc, N, L, din, 2 * LN, LN, npoly / 2, dout, 2, 0, h->stream);
-    else if (which == 1)
-        launch_scale_pq_expand(h->d_dc, N, L, din, 2 * LN, LN, npoly / 2, dout, 2, 0, h->stream);
-    else
-        launch_scale_round(h->d_dc, N, L, din, npoly / 3, dout, 3 * LN, dout + 2 * LN, 3 * LN, h->stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(out, dout, wout * sizeof(u64), hipMemcpyDeviceToHost));
-    return PIEHIP_OK;
-}
-
-// ---- FHEHIPPIE: the rotation-based sibling operator (FHEHIPPIE.{hpp,cpp}) ---------------------------------------
-static int rot_map_device(piehip_ctx *h, int32_t index, u32 **out)
-{
-    auto it = h->rotmaps.find(index);
-    if (it != h->rotmaps.end()) {
-        *out = it->second;
-        return PIEHIP_OK;
-    }
-    uint32_t g = 1;
-    int rc = piehip_rotation_galois(h, index, &g);
-    if (rc) return rc;
-    std::vector<u32> map = h->hp.automorph_map(g);
-    u32 *d = nullptr;
-    if (hipMalloc((void **)&d, sizeof(u32) * h->hp.N) != hipSuccess) return fail(PIEHIP_ENOMEM, "hipMalloc failed (rotation map)");
-    if (hipMemcpy(d, map.data(), sizeof(u32) * h->hp.N, hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(d);
-        return fail(PIEHIP_EHIP, "rotation map upload failed");
-    }
-    h->rotmaps[index] = d;
-    *out = d;
-    return PIEHIP_OK;
-}
-
-int piehip_load_rotation_keys(piehip_handle h, uint32_t nkeys, const int32_t *indices, const uint64_t *keys)
-{
-    NEED(h);
-    if (!nkeys || !indices || !keys) return fail(PIEHIP_EINVAL, "null operand");
-    HIPCHK(hipSetDevice(h->device));
-    const size_t words = (size_t)h->hp.L * 2 * h->LN();
-    for (u32 i = 0; i < nkeys; i++) {
-        uint32_t g = 1;
-        int rc = piehip_rotation_galois(h, indices[i], &g);
-        if (rc) return rc;
-        if (g == 1) return fail(PIEHIP_EINVAL, "rotation index is a multiple of the row length");
-        u64 *&d = h->rotkeys[indices[i]];
-        if (!d && (rc = dev_alloc(&d, words))) {
-            h->rotkeys.erase(indices[i]);
-            return rc;
-        }
-        HIPCHK(hipMemcpy(d, keys + (size_t)i * words, words * sizeof(u64), hipMemcpyHostToDevice));
-    }
-    dev_free(&h->fp_negkeys);  // rebuilt from the new keys by the next run
-    return PIEHIP_OK;
-}
-
-int piehip_fhepie_load_table(piehip_handle h, uint32_t npie, uint32_t K, uint32_t b, uint32_t E, const int64_t *slots,
-                             const int64_t *masks)
-{
-    NEED(h);
-    if (!slots || !masks) return fail(PIEHIP_EINVAL, "null operand");
-    if (!npie || !K || !b || !E) return fail(PIEHIP_EINVAL, "empty table");
-    // FHEHIPPIE.cpp:13-16: the bin size has to equal the number of bins per hash function
-    if (b != E) return fail(PIEHIP_EINVAL, "for FHE PIE the size of a cuckoo bin has to be equal to the number of bins per hash function");
-    if (E + 1 > h->hp.N / 2) return fail(PIEHIP_EINVAL, "E + 1 slots exceed one row of the packed encoding");
-    HIPCHK(hipSetDevice(h->device));
-    const u64 t = h->hp.t;
-    const size_t LN = h->LN();
-    const size_t npt = (size_t)npie * K * b, nmask = (size_t)npie * K;
-    for (size_t i = 0; i < npt * (E + 1); i++)
-        if ((u64)(slots[i] < 0 ? -slots[i] : slots[i]) >= t) return fail(PIEHIP_EINVAL, "slot value out of range for the plaintext modulus");
-    for (size_t i = 0; i < nmask * b; i++)
-        if (masks[i] <= 0 || (u64)masks[i] >= t) return fail(PIEHIP_EINVAL, "mask values must lie in [1, t-1]");
-    dev_free(&h->fp_pt);
-    dev_free(&h->fp_mask);
-    dev_free(&h->fp_idx);
-    dev_free(&h->fp_out);
-    h->fp_npie = 0;
-    int rc;
-    if ((rc = dev_alloc(&h->fp_pt, npt * LN))) return rc;
-    if ((rc = dev_alloc(&h->fp_mask, nmask * LN))) return rc;
-    if (!h->fp_e0 && (rc = dev_alloc(&h->fp_e0, LN))) return rc;
-    if ((rc = dev_alloc(&h->fp_idx, nmask * 2 * LN))) return rc;
-    if ((rc = dev_alloc(&h->fp_out, nmask * 2 * LN))) return rc;
-    Tmp tmp;
-    TMPGET(d_slots, npt * (E + 1));
-    TMPGET(d_masks, nmask * b);
-    TMPGET(d_one, 1);
-    const int64_t one = 1;
-    HIPCHK(hipMemcpy(d_slots, slots, sizeof(int64_t) * npt * (E + 1), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_masks, masks, sizeof(int64_t) * nmask * b, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_one, &one, sizeof(int64_t), hipMemcpyHostToDevice));
-    if ((rc = encode_on_device(h, (const int64_t *)d_slots, (u32)npt, E + 1, h->fp_pt))) return rc;
-    if ((rc = encode_on_device(h, (const int64_t *)d_masks, (u32)nmask, b, h->fp_mask))) return rc;
-    if ((rc = encode_on_device(h, (const int64_t *)d_one, 1, 1, h->fp_e0))) return rc;
-    h->fp_npie = npie;
-    h->fp_K = K;
-    h->fp_b = b;
-    h->fp_E = E;
-    dev_free(&h->fp_negkeys);
-    return PIEHIP_OK;
-}
-
-int piehip_fhepie_set_index(piehip_handle h, const uint64_t *idx)
-{
-    NEED(h);
-    if (!idx) return fail(PIEHIP_EINVAL, "null index");
-    if (!h->fp_npie) return fail(PIEHIP_ESTATE, "no table loaded");
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemcpy(h->fp_idx, idx, sizeof(u64) * (size_t)h->fp_npie * h->fp_K * 2 * h->LN(), hipMemcpyHostToDevice));
-    return PIEHIP_OK;
-}
-
-// FHEHIPPIE::run (FHEHIPPIE.cpp:61-77) for npie operators at once, hash function by hash function:
-//   prod[pie][bin] = idx[pie][hf] (.) pt[pie][hf][bin]                       EvalInnerProduct: EvalMult ...
-//   R = ceil(log2(b)) times: prod += rotate(prod, 2^r)                       ... then EvalSum over batchSize = #bins
-//   merged[pie] = sum_bin rotate(prod[pie][bin] (.) e0, -bin)                EvalMerge
-//   out[pie][hf] = merged (.) mask[pie][hf]                                  EvalMult(.., preCalcRandomMask)
-int piehip_fhepie_run(piehip_handle h)
-{
-    NEED(h);
-    if (!h->fp_npie) return fail(PIEHIP_ESTATE, "no table loaded");
-    HIPCHK(hipSetDevice(h->device));
-    const u32 N = h->hp.N, L = h->hp.L, npie = h->fp_npie, K = h->fp_K, b = h->fp_b;
-    const size_t LN = h->LN(), keyw = (size_t)L * 2 * LN;
-    const u32 nb = npie * b;
-    u32 R = 0;
-    while ((1u << R) < b) R++;  // EvalSum(ct, batchSize = vectorizedCT[hf].size()): ceil(log2) rotate-and-add steps
-    std::vector<const u64 *> sumkeys(R);
-    std::vector<u32 *> summaps(R);
-    int rc;
-    for (u32 r = 0; r < R; r++) {
-        auto it = h->rotkeys.find((int32_t)(1u << r));
-        if (it == h->rotkeys.end()) return fail(PIEHIP_ESTATE, "EvalSum key for rotation " + std::to_string(1u << r) + " not loaded");
-        sumkeys[r] = it->second;
-        if ((rc = rot_map_device(h, (int32_t)(1u << r), &summaps[r]))) return rc;
-    }
-    if (!h->fp_negkeys && b > 1) {  // keys / maps of rotations -1 .. -(b-1), position r holds rotation -r
-        if ((rc = dev_alloc(&h->fp_negkeys, (size_t)b * keyw))) return rc;
-        if (h->fp_negmaps) (void)hipFree(h->fp_negmaps);
-        h->fp_negmaps = nullptr;
-        if (hipMalloc((void **)&h->fp_negmaps, sizeof(u32) * (size_t)b * N) != hipSuccess) return fail(PIEHIP_ENOMEM, "hipMalloc failed (merge maps)");
-        for (u32 r = 1; r < b; r++) {
-            auto it = h->rotkeys.find(-(int32_t)r);
-            if (it == h->rotkeys.end()) {
-                dev_free(&h->fp_negkeys);
-                return fail(PIEHIP_ESTATE, "EvalAtIndex key for rotation -" + std::to_string(r) + " not loaded");
-            }
-            u32 *dm = nullptr;
-            if ((rc = rot_map_device(h, -(int32_t)r, &dm))) return rc;
-            HIPCHK(hipMemcpyAsync(h->fp_negkeys + (size_t)r * keyw, it->second, keyw * sizeof(u64), hipMemcpyDeviceToDevice, h->stream));
-            HIPCHK(hipMemcpyAsync(h->fp_negmaps + (size_t)r * N, dm, sizeof(u32) * N, hipMemcpyDeviceToDevice, h->stream));
-        }
-        // position 0 is never rotated: its digits are zero, any valid key / map will do
-        HIPCHK(hipMemcpyAsync(h->fp_negkeys, h->fp_negkeys + keyw, keyw * sizeof(u64), hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->fp_negmaps, h->fp_negmaps + N, sizeof(u32) * N, hipMemcpyDeviceToDevice, h->stream));
-    }
-    MulWs w;
-    u64 *prod = nullptr;
-    auto cleanup = [&]() {
-        ws_free(w);
-        dev_free(&prod);
-    };
-    // only d01 / d2c / dig of the workspace are used here
-    w.nb = nb;
-    if ((rc = dev_alloc(&w.d01, (size_t)nb * 2 * LN)) || (rc = dev_alloc(&w.d2c, (size_t)nb * LN)) ||
-        (rc = dev_alloc(&w.dig, (size_t)nb * L * LN)) || (rc = dev_alloc(&prod, (size_t)nb * 2 * LN))) {
-        cleanup();
-        return rc;
-    }
-    h->pool_used = 0;
-    h->recs.clear();
-    const double W = 8.0 * N;
-    for (u32 hf = 0; hf < K; hf++) {
-        {
-            ProfScope ps(h, PIEHIP_K_MASK, W * nb * 5.0 * L);
-            launch_bcast_mul_plain(h->d_dc, N, L, h->fp_idx + (size_t)hf * 2 * LN, (size_t)K * 2 * LN, b,
-                                   h->fp_pt + (size_t)hf * b * LN, (size_t)K * b * LN, LN, prod, nb, h->stream);
-        }
-        for (u32 r = 0; r < R; r++) {
-            {
-                ProfScope ps(h, PIEHIP_K_AUTOMORPH, W * nb * 7.0 * L);
-                launch_rot_prepare(h->d_dc, N, L, prod, summaps[r], 1, true, false, w.d01, w.d2c, nb, h->stream);
-            }
-            ntt(h, w.d2c, nb * L, 0, L, true);
-            enqueue_keyswitch(h, w, nb, sumkeys[r], nullptr, prod);
-        }
-        if (b > 1) {
-            {
-                ProfScope ps(h, PIEHIP_K_MASK, W * nb * 5.0 * L);
-                launch_ct_mul_plain(h->d_dc, N, L, prod, h->fp_e0, 0, prod, nb, h->stream);
-            }
-            {
-                ProfScope ps(h, PIEHIP_K_AUTOMORPH, W * nb * 5.0 * L);
-                launch_rot_prepare(h->d_dc, N, L, prod, h->fp_negmaps, b, false, true, w.d01, w.d2c, nb, h->stream);
-            }
-            ntt(h, w.d2c, nb * L, 0, L, true);
-            enqueue_keyswitch(h, w, nb, h->fp_negkeys, nullptr, prod, false, false, keyw, b);
-        } else {
-            ProfScope ps(h, PIEHIP_K_MASK, W * nb * 5.0 * L);
-            launch_ct_mul_plain(h->d_dc, N, L, prod, h->fp_e0, 0, prod, nb, h->stream);
-        }
-        {
-            ProfScope ps(h, PIEHIP_K_MASK, W * (nb * 2.0 * L + npie * 3.0 * L));
-            launch_sum_mul_plain(h->d_dc, N, L, prod, b, h->fp_mask + (size_t)hf * LN, (size_t)K * LN, h->fp_out + (size_t)hf * 2 * LN,
-                                 (size_t)K * 2 * LN, npie, h->stream);
-        }
-    }
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    cleanup();
-    if (e != hipSuccess) return fail(PIEHIP_EHIP, std::string("fhepie_run: ") + hipGetErrorString(e));
-    return PIEHIP_OK;
-}
-
-int piehip_fhepie_get_results(piehip_handle h, uint64_t *out)
-{
-    NEED(h);
-    if (!out) return fail(PIEHIP_EINVAL, "null out");
-    if (!h->fp_npie) return fail(PIEHIP_ESTATE, "no table loaded");
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemcpy(out, h->fp_out, sizeof(u64) * (size_t)h->fp_npie * h->fp_K * 2 * h->LN(), hipMemcpyDeviceToHost));
-    return PIEHIP_OK;
-}
-
-int piehip_bench_ntt(piehip_handle h, uint32_t nlimbs, uint32_t mod_count, int flags, uint32_t iters, double *ms_per_launch)
-{
-    NEED(h);
-    if (!nlimbs || !mod_count || mod_count > h->hp.M || !iters || !ms_per_launch) return fail(PIEHIP_EINVAL, "bad argument");
-    HIPCHK(hipSetDevice(h->device));
-    Tmp tmp;
-    const u32 N = h->hp.N;
-    const size_t words = (size_t)nlimbs * N;
-    TMPGET(d, words);
-    {   // residues below the smallest modulus are valid for every limb
-        std::vector<u64> host(words);
-        u64 lo = h->hp.moduli[0];
-        for (u32 a = 1; a < mod_count; a++) lo = h->hp.moduli[a] < lo ? h->hp.moduli[a] : lo;
-        u64 s = 0x9E3779B97F4A7C15ULL;
-        for (size_t i = 0; i < words; i++) {
-            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
-            host[i] = s % lo;
-        }
-        HIPCHK(hipMemcpy(d, host.data(), words * sizeof(u64), hipMemcpyHostToDevice));
-    }
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
-    const bool inverse = (flags & 1) != 0, sigma = (flags & 2) != 0 && h->sigma_on;
-    launch_ntt(h->plan, d, nlimbs, 0, mod_count, inverse, h->stream, sigma);  // warm-up
-    HIPCHK(hipEventRecord(e0, h->stream));
-    for (u32 i = 0; i < iters; i++) launch_ntt(h->plan, d, nlimbs, 0, mod_count, inverse, h->stream, sigma);
-    HIPCHK(hipEventRecord(e1, h->stream));
-    HIPCHK(hipEventSynchronize(e1));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    *ms_per_launch = (double)ms / iters;
-    return PIEHIP_OK;
-}
-
-// ---- client harness --------------------------------------------------------------------------------------------------
-namespace {
-// xoshiro256** seeded through splitmix64, rejection sampling on the smallest covering mask
-struct HostRng {
-    u64 s[4];
-    explicit HostRng(u64 seed)
-    {
-        for (int i = 0; i < 4; i++) {
-            seed += 0x9E3779B97F4A7C15ULL;
-            u64 z = seed;
-            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-            s[i] = z ^ (z >> 31);
-        }
-    }
-    static u64 rotl(u64 x, int k) { return (x << k) | (x >> (64 - k)); }
-    u64 next()
-    {
-        const u64 result = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
-        s[2] ^= s[0];
-        s[3] ^= s[1];
-        s[1] ^= s[2];
-        s[0] ^= s[3];
-        s[2] ^= t;
-        s[3] = rotl(s[3], 45);
-        return result;
-    }
-    u64 below(u64 bound)
-    {
-        u64 mask = bound - 1;
-        mask |= mask >> 1;
-        mask |= mask >> 2;
-        mask |= mask >> 4;
-        mask |= mask >> 8;
-        mask |= mask >> 16;
-        mask |= mask >> 32;
-        for (;;) {
-            const u64 v = next() & mask;
-            if (v < bound) return v;
-        }
-    }
-};
-void sample_uniform(HostRng &r, const HostParams &hp, u64 *a)  // [L][N], independent per limb
-{
-    for (u32 i = 0; i < hp.L; i++)
-        for (u32 j = 0; j < hp.N; j++) a[(size_t)i * hp.N + j] = r.below(hp.moduli[i]);
-}
-void sample_error(HostRng &r, u32 N, int32_t *e)  // centred binomial, variance 10
-{
-    for (u32 j = 0; j < N; j++) {
-        const u64 x = r.next();
-        e[j] = __builtin_popcountll(x & 0xFFFFF) - __builtin_popcountll((x >> 20) & 0xFFFFF);
-    }
-}
-}  // namespace
-
-int piehip_client_keygen(piehip_handle h, uint64_t seed, uint64_t *sk)
-{
-    NEED(h);
-    if (!sk) return fail(PIEHIP_EINVAL, "null sk");
-    HIPCHK(hipSetDevice(h->device));
-    const u32 N = h->hp.N, L = h->hp.L;
-    HostRng r(seed);
-    std::vector<u64> host((size_t)L * N);
-    for (u32 j = 0; j < N; j++) {
-        const int v = (int)r.below(3) - 1;
-        for (u32 i = 0; i < L; i++) host[(size_t)i * N + j] = v >= 0 ? (u64)v : h->hp.moduli[i] - 1;
-    }
-    Tmp tmp;
-    TMPGET(d, (size_t)L * N);
-    HIPCHK(hipMemcpy(d, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice));
-    launch_ntt(h->plan, d, L, 0, L, false, h->stream);
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(sk, d, host.size() * sizeof(u64), hipMemcpyDeviceToHost));
-    return PIEHIP_OK;
-}
-
-// BV key-switching key from s_from to sk (oracle: ks_keygen): row i = (e_i - a_i s + [j == i] s_from, a_i).
-// g == 0: s_from = s^2 (EvalMultKeyGen); otherwise s_from = s(X^g) (EvalAtIndexKeyGen / EvalSumKeyGen).
-static int client_ks_keygen(piehip_ctx *h, const uint64_t *sk, uint32_t g, uint64_t seed, uint64_t *out)
-{
-    HIPCHK(hipSetDevice(h->device));
-    const u32 N = h->hp.N, L = h->hp.L;
-    const size_t LN = h->LN();
-    HostRng r(seed);
-    std::vector<u64> ks((size_t)L * 2 * LN), e((size_t)L * LN);
-    std::vector<int32_t> ev(N);
-    for (u32 i = 0; i < L; i++) {
-        sample_uniform(r, h->hp, &ks[((size_t)i * 2 + 1) * LN]);
-        sample_error(r, N, ev.data());
-        for (u32 l = 0; l < L; l++)
-            for (u32 j = 0; j < N; j++) e[(size_t)i * LN + (size_t)l * N + j] = ev[j] >= 0 ? (u64)ev[j] : h->hp.moduli[l] - (u64)(-ev[j]);
-    }
-    Tmp tmp;
-    TMPGET(d_ks, ks.size());
-    TMPGET(d_e, e.size());
-    TMPGET(d_sk, LN);
-    TMPGET(d_s2, LN);
-    TMPGET(d_mapw, (N + 1) / 2 + 1);
-    HIPCHK(hipMemcpy(d_ks, ks.data(), ks.size() * sizeof(u64), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_e, e.data(), e.size() * sizeof(u64), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_sk, sk, LN * sizeof(u64), hipMemcpyHostToDevice));
-    launch_ntt(h->plan, d_e, L * L, 0, L, false, h->stream);
-    if (g) {
-        std::vector<u32> map = h->hp.automorph_map(g);
-        HIPCHK(hipMemcpy(d_mapw, map.data(), sizeof(u32) * N, hipMemcpyHostToDevice));
-        launch_permute(N, d_sk, (const u32 *)d_mapw, d_s2, L, h->stream);
-    } else {
-        launch_square(h->d_dc, N, L, d_sk, d_s2, h->stream);
-    }
-    launch_ks_finish(h->d_dc, N, L, d_e, d_sk, d_s2, d_ks, h->stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(out, d_ks, ks.size() * sizeof(u64), hipMemcpyDeviceToHost));
-    return PIEHIP_OK;
-}
-
-int piehip_client_relin_keygen(piehip_handle h, const uint64_t *sk, uint64_t seed, uint64_t *evk)
-{
-    NEED(h);
-    if (!sk || !evk) return fail(PIEHIP_EINVAL, "null operand");
-    return client_ks_keygen(h, sk, 0, seed, evk);
-}
-
-int piehip_rotation_galois(piehip_handle h, int32_t index, uint32_t *g)
-{
-    NEED_RO(h);
-    if (!g) return fail(PIEHIP_EINVAL, "null out");
-    const u32 N = h->hp.N;
-    const u64 m2 = 2ULL * N;
-    u64 base = 5;
-    if (index < 0) base = powmod(5, N / 2 - 1, m2);  // 5 has order N/2 modulo 2N
-    const u64 k = (u64)(index < 0 ? -(int64_t)index : (int64_t)index);
-    *g = (u32)powmod(base, k % (N / 2 ? N / 2 : 1), m2);
-    return PIEHIP_OK;
-}
-
-int piehip_client_rot_keygen(piehip_handle h, const uint64_t *sk, int32_t index, uint64_t seed, uint64_t *rk)
-{
-    NEED(h);
-    if (!sk || !rk) return fail(PIEHIP_EINVAL, "null operand");
-    uint32_t g = 1;
-    int rc = piehip_rotation_galois(h, index, &g);
-    if (rc) return rc;
-    if (g == 1) return fail(PIEHIP_EINVAL, "rotation index is a multiple of the row length");
-    return client_ks_keygen(h, sk, g, seed, rk);
-}
-
-int piehip_client_encrypt(piehip_handle h, const uint64_t *sk, const int64_t *slots, uint32_t nct, uint32_t B,
-                          const uint64_t *seeds, uint64_t *out)
-{
-    NEED(h);
-    if (!sk || !slots || !seeds || !out || !nct) return fail(PIEHIP_EINVAL, "null operand");
-    if (B > h->hp.N) return fail(PIEHIP_EINVAL, "batch size exceeds the ring dimension");
-    HIPCHK(hipSetDevice(h->device));
-    const u32 N = h->hp.N, L = h->hp.L, M = h->hp.M;
-    const size_t LN = h->LN();
-    const u64 t = h->hp.t;
-    for (size_t i = 0; i < (size_t)nct * B; i++)
-        if ((u64)(slots[i] < 0 ? -slots[i] : slots[i]) >= t) return fail(PIEHIP_EINVAL, "slot value out of range for the plaintext modulus");
-    // host staging, not zero-filled (the sampling threads touch their own parts): a[nct][L][N] and e[nct][N]
-    std::unique_ptr<u64[]> a_host(new u64[(size_t)nct * LN]);
-    std::unique_ptr<int32_t[]> ev(new int32_t[(size_t)nct * N]);
-    {
-        // every ciphertext has its own seed and draws a (uniform), then e, as a sequential client would: the ciphertexts are
-        // independent, so host threads share them out (2.4 M rejection-sampled words for the 29 ciphertexts of a C3 query)
-        auto sample = [&](u32 c0, u32 c1) {
-            for (u32 c = c0; c < c1; c++) {
-                HostRng r(seeds[c]);
-                sample_uniform(r, h->hp, &a_host[(size_t)c * LN]);
-                sample_error(r, N, &ev[(size_t)c * N]);
-            }
-        };
-        const u32 hw = std::thread::hardware_concurrency();
-        const u32 nth = std::max(1u, std::min(std::min(nct, hw ? hw : 1u), 16u));
-        std::vector<std::thread> pool;
-        for (u32 i = 1; i < nth; i++) pool.emplace_back(sample, (u32)((u64)nct * i / nth), (u32)((u64)nct * (i + 1) / nth));
-        sample(0, nct / nth);
-        for (auto &th : pool) th.join();
-    }
-    const size_t ct_words = (size_t)nct * 2 * LN;
-    Tmp tmp(h);
-    TMPGET(d_out, ct_words);
-    TMPGET(d_sk, LN);
-    TMPGET(d_slotsw, (size_t)nct * B);
-    TMPGET(d_u, (size_t)nct * N);
-    TMPGET(d_em, (size_t)nct * LN);
-    TMPGET(d_evw, ((size_t)nct * N + 1) / 2 + 1);
-    TMPGET(d_a, (size_t)nct * LN);
-    HIPCHK(hipMemcpy(d_a, a_host.get(), (size_t)nct * LN * sizeof(u64), hipMemcpyHostToDevice));  // enc_finish puts it into the c1 halves
-    HIPCHK(hipMemcpy(d_sk, sk, LN * sizeof(u64), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_slotsw, slots, sizeof(int64_t) * (size_t)nct * B, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_evw, ev.get(), sizeof(int32_t) * (size_t)nct * N, hipMemcpyHostToDevice));
-    launch_encode_scatter(h->d_dc, N, M, (const int64_t *)d_slotsw, B, h->d_inv_pos, d_u, nct, h->stream);
-    launch_ntt(h->plan, d_u, nct, M, 1, true, h->stream);  // coefficients mod t
-    launch_enc_message(h->d_dc, N, L, M, d_u, (const int32_t *)d_evw, d_em, nct, h->stream);
-    launch_ntt(h->plan, d_em, nct * L, 0, L, false, h->stream);
-    launch_enc_finish(h->d_dc, N, L, d_em, d_sk, d_a, d_out, nct, h->stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(out, d_out, ct_words * sizeof(u64), hipMemcpyDeviceToHost));
-    return PIEHIP_OK;
-}
-
-int piehip_client_decrypt(piehip_handle h, const uint64_t *sk, const uint64_t *ct, uint32_t nct, uint32_t B, int64_t *slots)
-{
-    NEED(h);
-    if (!sk || !ct || !slots || !nct) return fail(PIEHIP_EINVAL, "null operand");
-    if (B > h->hp.N) return fail(PIEHIP_EINVAL, "batch size exceeds the ring dimension");
-    HIPCHK(hipSetDevice(h->device));
-    const u32 N = h->hp.N, L = h->hp.L, M = h->hp.M;
-    const size_t LN = h->LN();
-    Tmp tmp;
-    TMPGET(d_ct, (size_t)nct * 2 * LN);
-    TMPGET(d_sk, LN);
-    TMPGET(d_x, (size_t)nct * LN);
-    TMPGET(d_u, (size_t)nct * N);
-    TMPGET(d_slotsw, (size_t)nct * B);
-    TMPGET(d_posw, (N + 1) / 2 + 1);
-    HIPCHK(hipMemcpy(d_ct, ct, (size_t)nct * 2 * LN * sizeof(u64), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_sk, sk, LN * sizeof(u64), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_posw, h->hp.slot_pos.data(), sizeof(u32) * N, hipMemcpyHostToDevice));
-    launch_dec_dot(h->d_dc, N, L, d_ct, d_sk, d_x, nct, h->stream);
-    launch_ntt(h->plan, d_x, nct * L, 0, L, true, h->stream);
-    launch_dec_round(h->d_dc, N, L, M, d_x, d_u, nct, h->stream);
-    launch_ntt(h->plan, d_u, nct, M, 1, false, h->stream);
-    launch_decode_gather(h->d_dc, N, M, d_u, (const u32 *)d_posw, B, (int64_t *)d_slotsw, nct, h->stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(slots, d_slotsw, sizeof(int64_t) * (size_t)nct * B, hipMemcpyDeviceToHost));
-    return PIEHIP_OK;
-}
-
-int piehip_set_profiling(piehip_handle h, int on)
-{
-    NEED_RO(h);
-    h->profiling = on != 0;
-    h->recs.clear();
-    h->pool_used = 0;
-    return PIEHIP_OK;
-}
-
-int piehip_profile_read(piehip_handle h, uint32_t *launches, double *ms, double *alg_bytes)
-{
-    NEED_RO(h);
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    for (int k = 0; k < PIEHIP_NKERNELS; k++) {
-        if (launches) launches[k] = 0;
-        if (ms) ms[k] = 0;
-        if (alg_bytes) alg_bytes[k] = 0;
-    }
-    for (const ProfRec &r : h->recs) {
-        float t = 0;
-        HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
-        if (launches) launches[r.k]++;
-        if (ms) ms[r.k] += t;
-        if (alg_bytes) alg_bytes[r.k] += r.bytes;
-    }
     return PIEHIP_OK;
 }
 
