@@ -148,22 +148,33 @@ int piehip_run_host(piehip_handle h, const uint64_t *idx /*[K][E][2][L][N]*/, co
  * piehip_attach_database): _async returns once the uploads, the evaluation and the downloads are queued -- with page-locked
  * arrays (piehip_host_buffers) nothing in it waits for the device -- and _wait blocks until `results` is complete.  While
  * slot A evaluates, slot B's query crosses PCIe: the path is bound by the 29 MiB upload per query, not by upload + run +
- * download.  The arrays must stay valid and unchanged until _wait returns. */
+ * download.  The arrays must stay valid and unchanged until _wait returns.
+ * A handle with a batch of nq queries (piehip_set_query_batch) takes idx[nq][K][E][2][L][N], minus[nq][2][L][N] and writes
+ * results[b][nq][2][L][N]. */
 int piehip_run_host_async(piehip_handle h, const uint64_t *idx, const uint64_t *minus, uint64_t *results);
 int piehip_run_host_wait(piehip_handle h);
-/* page-locked staging arrays owned by the handle (valid until the database shape changes or the handle is destroyed) */
+/* page-locked staging arrays owned by the handle (valid until the database shape or the batch size changes, or the handle is
+ * destroyed).  _q: the staging of query q of a batch -- every query has its own index matrix and minus element; `results` is the
+ * one result array of the handle, [b][nq][2][L][N] (the nq result ciphertexts of a bin layer are adjacent), for every q. */
 int piehip_host_buffers(piehip_handle h, uint64_t **idx, uint64_t **minus, uint64_t **results);
+int piehip_host_buffers_q(piehip_handle h, uint32_t q, uint64_t **idx, uint64_t **minus, uint64_t **results);
 /* piehip_run_host_async piece by piece, for a server that receives the query message by message -- one message per ciphertext,
  * the minus element first (BatchedFHEPSIServer.cpp:94-95,114-141): every piece starts its upload as soon as the deserialiser has
  * written it (into the page-locked arrays above, or any host memory that stays valid until piehip_run_host_wait), so the 29 MiB of
  * a C3 query cross PCIe while the remaining messages are still arriving, i.e. before the reference's timer starts (.cpp:98-99).
- *   piehip_stage_minus      the minus element [2][L][N]
- *   piehip_stage_index_row  row `row` (one inner hash function) of the index matrix, [E][2][L][N]
- *   piehip_run_staged       setMinusCompareElement + setIndex + run + getResultList on the staged pieces: stage A of row h waits
- *                           for that row only; results (may be NULL) are complete after piehip_run_host_wait.
+ *   piehip_stage_minus(_q)      the minus element [2][L][N] (of query q of the batch; pieces of different queries in any order)
+ *   piehip_stage_index_row(_q)  row `row` (one inner hash function) of the index matrix, [E][2][L][N]
+ *   piehip_run_staged           setMinusCompareElement + setIndex + run + getResultList on the staged pieces: stage A of row h waits
+ *                               for row h of every query of the batch only; results ([b][nq][2][L][N], may be NULL) are complete
+ *                               after piehip_run_host_wait.
+ *   piehip_stage_reset          drops a partial staging sequence (a receive failed between two pieces): the next piece begins a
+ *                               new one.  Staging a piece again before the run simply replaces it.
  * PIEHIP_ESTATE when a piece is missing.  piehip_run_host_async is exactly: stage_minus, stage_index_row for every row, run_staged. */
 int piehip_stage_minus(piehip_handle h, const uint64_t *minus);
 int piehip_stage_index_row(piehip_handle h, uint32_t row, const uint64_t *row_data);
+int piehip_stage_minus_q(piehip_handle h, uint32_t q, const uint64_t *minus);
+int piehip_stage_index_row_q(piehip_handle h, uint32_t q, uint32_t row, const uint64_t *row_data);
+int piehip_stage_reset(piehip_handle h);
 int piehip_run_staged(piehip_handle h, uint64_t *results);
 /* Stream order.  run() works on the handle's own queues (piehip_set_run_streams); it waits for the handle's stream
  * where it must (new inputs; the result buffer), and the handle's stream waits for the run in the next call of any
@@ -199,10 +210,13 @@ int piehip_attach_database(piehip_handle h, piehip_handle owner);
  *   piehip_set_*_q           inputs of query q < nq (q = 0: the plain setters above)
  *   results                  piehip_run / piehip_run_into / piehip_get_results then use rows [b][nq][2][L][N]: the nq result
  *                            ciphertexts of a bin layer are adjacent
- * With nq > 1 the host-buffer entry points (piehip_run_host*, piehip_stage_*, piehip_host_buffers) and the captured graph
- * are not available (PIEHIP_ESTATE / eager launches). */
+ *   piehip_load_relin_key_q  the EvalMult key of query q's client (BatchedFHEPSIServer.cpp:45-49: every client sends its own);
+ *                            queries without one use the handle's key.  Sized by the batch: load again after piehip_set_query_batch
+ * The host-memory path takes batches too: piehip_host_buffers_q / piehip_stage_*_q / piehip_run_staged / piehip_run_host* below.
+ * Only the captured graph (piehip_set_graph) is limited to one query per run(). */
 int piehip_set_query_batch(piehip_handle h, uint32_t nq);
 int piehip_get_query_batch(piehip_handle h, uint32_t *nq);
+int piehip_load_relin_key_q(piehip_handle h, uint32_t q, const uint64_t *evk /*[L][2][L][N]*/);
 int piehip_set_index_q(piehip_handle h, uint32_t q, const uint64_t *idx /*[K][E][2][L][N]*/);
 int piehip_set_minus_q(piehip_handle h, uint32_t q, const uint64_t *minus /*[2][L][N]*/);
 int piehip_set_index_device_q(piehip_handle h, uint32_t q, const void *d_idx);

@@ -181,7 +181,11 @@ void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const u64 *y,
             }
             if (!digits_ready) ntt(h, w.d01, nb * 2 * L, 0, L, false, true, true, &ex);
         }
-        enqueue_keyswitch(h, w, nb, h->sigma_on ? h->d_evk_sigma : h->d_evk, mask, out, true, true, 0, 1, out_is_result, digits_ready);
+        if (h->key_group > 1)  // a batch whose queries bring their own keys (piehip_load_relin_key_q)
+            enqueue_keyswitch(h, w, nb, h->sigma_on ? h->d_evkq_sigma : h->d_evkq, mask, out, true, true, (size_t)L * 2 * LN, h->key_group,
+                              out_is_result, digits_ready);
+        else
+            enqueue_keyswitch(h, w, nb, h->sigma_on ? h->d_evk_sigma : h->d_evk, mask, out, true, true, 0, 1, out_is_result, digits_ready);
     } else {
         {
             ProfScope ps(h, PIEHIP_K_SCALE, W * nb * (3.0 * M + 3.0 * L));
@@ -395,6 +399,8 @@ int piehip_destroy(piehip_handle h)
     if (h->d_inv_pos) (void)hipFree(h->d_inv_pos);
     if (h->d_sigma_inv) (void)hipFree(h->d_sigma_inv);
     dev_free(&h->d_evk_sigma);
+    dev_free(&h->d_evkq);
+    dev_free(&h->d_evkq_sigma);
     dev_free(&h->d_masks_sigma);
     dev_free(&h->d_hash_tbl);
     dev_free(&h->arena);
@@ -412,16 +418,7 @@ int piehip_destroy(piehip_handle h)
         (void)hipStreamDestroy(s);
     }
     drop_graph(h);
-    if (h->copy_stream) {
-        (void)hipStreamSynchronize(h->copy_stream);
-        (void)hipStreamDestroy(h->copy_stream);
-    }
-    for (hipEvent_t e : h->ev_h2d) (void)hipEventDestroy(e);
-    if (h->ev_copy_gate) (void)hipEventDestroy(h->ev_copy_gate);
-    if (h->ev_minus_h2d) (void)hipEventDestroy(h->ev_minus_h2d);
-    if (h->pin_idx) (void)hipHostFree(h->pin_idx);
-    if (h->pin_minus) (void)hipHostFree(h->pin_minus);
-    if (h->pin_res) (void)hipHostFree(h->pin_res);
+    free_host_path(h);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (hipEvent_t e : h->ev_join) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -957,6 +954,12 @@ int piehip_set_query_batch(piehip_handle h, uint32_t nq)
     HIPCHK(hipStreamSynchronize(h->stream));
     drop_graph(h);
     h->stage_open = false;
+    // caller-owned device pointers of queries outside the new batch are forgotten (they may be freed by now); a later, larger
+    // batch must set them again.  Per-query keys are sized by the batch: load them again after a change.
+    for (u32 q = nq; q < STAGE_A_MAX_QUERIES; q++) h->bq_idx[q] = h->bq_minus[q] = nullptr;
+    dev_free(&h->d_evkq);
+    dev_free(&h->d_evkq_sigma);
+    h->evkq_n = h->evkq_loaded = 0;
     h->nq = nq;
     if (!h->K) return PIEHIP_OK;  // the database's arrival sizes the workspace
     free_workspace(h);
@@ -1023,6 +1026,56 @@ int piehip_set_minus_q(piehip_handle h, uint32_t q, const uint64_t *minus)
     HIPCHK(hipMemcpyAsync(h->bq_minus_own[q], minus, words * sizeof(u64), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->bq_minus[q] = h->bq_minus_own[q];
+    return PIEHIP_OK;
+}
+
+}  // extern "C"
+namespace piehip {
+int query_input_buffers(piehip_ctx *h, u32 q, u64 **d_idx, u64 **d_minus)
+{
+    if (!h->K) return fail(PIEHIP_ESTATE, "load the database before the index matrix");
+    if (q >= h->nq) return fail(PIEHIP_EINVAL, "query index outside the batch (piehip_set_query_batch)");
+    u64 **pi = q ? &h->bq_idx_own[q] : &h->d_idx_own, **pm = q ? &h->bq_minus_own[q] : &h->d_minus_own;
+    int rc;
+    if (!*pi && (rc = dev_alloc(pi, (size_t)h->K * h->E * 2 * h->LN()))) return rc;
+    if (!*pm && (rc = dev_alloc(pm, 2 * h->LN()))) return rc;
+    *d_idx = *pi;
+    *d_minus = *pm;
+    return PIEHIP_OK;
+}
+}  // namespace piehip
+extern "C" {
+
+// The queries of a batch come from different clients (BatchedFHEPSIServer.cpp:94-95: one client per connection), and every client
+// has its own EvalMult key (.cpp:45-49): query q's key switch takes key q.  The key-switch kernel already selects its key per
+// ciphertext row (FHEHIPPIE's EvalMerge: one rotation key per position); rows of a batch are [bin layer][query], so row r
+// takes key r % nq.
+int piehip_load_relin_key_q(piehip_handle h, uint32_t q, const uint64_t *evk)
+{
+    NEED(h);
+    if (!evk) return fail(PIEHIP_EINVAL, "null evk");
+    if (q >= h->nq) return fail(PIEHIP_EINVAL, "query index outside the batch (piehip_set_query_batch)");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t words = (size_t)h->hp.L * 2 * h->LN();
+    int rc;
+    if (!h->d_evkq || h->evkq_n != h->nq) {
+        dev_free(&h->d_evkq);
+        dev_free(&h->d_evkq_sigma);
+        h->evkq_n = h->evkq_loaded = 0;
+        if ((rc = dev_alloc(&h->d_evkq, words * h->nq))) return rc;
+        if (h->sigma_on && (rc = dev_alloc(&h->d_evkq_sigma, words * h->nq))) return rc;
+        h->evkq_n = h->nq;
+        // queries without a key of their own use the handle's (piehip_load_relin_key), if it has one
+        for (u32 i = 0; i < h->nq && h->d_evk; i++) {
+            HIPCHK(hipMemcpyAsync(h->d_evkq + i * words, h->d_evk, words * sizeof(u64), hipMemcpyDeviceToDevice, h->stream));
+            if (h->sigma_on)
+                HIPCHK(hipMemcpyAsync(h->d_evkq_sigma + i * words, h->d_evk_sigma, words * sizeof(u64), hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
+    HIPCHK(hipMemcpyAsync(h->d_evkq + q * words, evk, words * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    if (h->sigma_on) launch_permute(h->hp.N, h->d_evkq + q * words, h->d_sigma_inv, h->d_evkq_sigma + q * words, h->hp.L * 2 * h->hp.L, h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->evkq_loaded |= 1u << q;
     return PIEHIP_OK;
 }
 
@@ -1097,24 +1150,20 @@ static void enqueue_run_bins(piehip_ctx *h, u32 b0, u32 nb, u64 *results)
     const u64 *masks = (h->sigma_on ? h->d_masks_sigma : h->d_masks) + (size_t)b0 * LN;
     struct MaskDiv {
         piehip_ctx *h;
-        ~MaskDiv() { h->mask_div = 1; }
+        ~MaskDiv() { h->mask_div = h->key_group = 1; }
     } mask_div_scope{h};
     h->mask_div = nq;
+    h->key_group = (nq > 1 && h->d_evkq && h->evkq_n == nq) ? nq : 1;  // per-query EvalMult keys: row r of a group is query r % nq
     {   // stage A: all inner products of these bin layers in one launch (BatchedFHEHIPPIE.cpp:101-116)
         ProfScope ps(h, PIEHIP_K_STAGE_A, W * ((double)layers * K * E * L + nq * ((double)K * E * 2 * L + 2.0 * L + (double)layers * K * 2 * L)));
+        StageAQueries qs = {};
+        qs.idx[0] = h->d_idx, qs.minus[0] = h->d_minus;
+        for (u32 q = 1; q < nq; q++) qs.idx[q] = h->bq_idx[q], qs.minus[q] = h->bq_minus[q];
+        const u64 *db = h->d_db + (size_t)b0 * E * LN;
         if (nq > 1) {
-            StageAQueries qs = {};
-            qs.idx[0] = h->d_idx, qs.minus[0] = h->d_minus;
-            for (u32 q = 1; q < nq; q++) qs.idx[q] = h->bq_idx[q], qs.minus[q] = h->bq_minus[q];
-            launch_stage_a_batch(h->d_dc, N, L, K, layers, E, qs, nq, h->d_db + (size_t)b0 * E * LN, acc, h->stream, h->small_moduli, b);
-        } else if (h->row_events) {
-            // the index matrix is still arriving over PCIe: one launch per inner hash function, each behind its own row
-            for (u32 hf = 0; hf < K; hf++) {
-                (void)hipStreamWaitEvent(h->stream, h->row_events[hf], 0);
-                launch_stage_a(h->d_dc, N, L, K, nb, E, h->d_idx, h->d_minus, h->d_db + (size_t)b0 * E * LN, acc, h->stream, h->small_moduli, b, hf, 1);
-            }
+            launch_stage_a_batch(h->d_dc, N, L, K, layers, E, qs, nq, db, acc, h->stream, h->small_moduli, b);
         } else {
-            launch_stage_a(h->d_dc, N, L, K, nb, E, h->d_idx, h->d_minus, h->d_db + (size_t)b0 * E * LN, acc, h->stream, h->small_moduli, b);
+            launch_stage_a(h->d_dc, N, L, K, nb, E, h->d_idx, h->d_minus, db, acc, h->stream, h->small_moduli, b);
         }
     }
     if (K == 1) {
@@ -1150,17 +1199,24 @@ static void enqueue_run_bins(piehip_ctx *h, u32 b0, u32 nb, u64 *results)
     }
 }
 
+// the result ciphertexts of bin layers [b0, b0 + nb) (rows [bin layer][query]) to the caller's host array, on the current queue
+static hipError_t download_rows(piehip_ctx *h, const u64 *d_results, u32 b0, u32 nb)
+{
+    const size_t row = (size_t)h->nq * 2 * h->LN();
+    return hipMemcpyAsync(h->host_results + (size_t)b0 * row, d_results + (size_t)b0 * row, (size_t)nb * row * sizeof(u64),
+                          hipMemcpyDeviceToHost, h->stream);
+}
+
 int piehip_run_into(piehip_handle h, void *d_results)
 {
     if (!h) return fail(PIEHIP_EINVAL, "null handle");
     if (!d_results) return fail(PIEHIP_EINVAL, "null result buffer");
     if (!h->K || !h->d_db) return fail(PIEHIP_ESTATE, "run: database not loaded");
     if (!h->d_acc || !h->ws.eqp) return fail(PIEHIP_ESTATE, "run: no workspace (an earlier allocation failed: piehip_set_query_batch / load)");
-    if (!h->d_evk && h->K > 1) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
+    if (!run_keys_loaded(h)) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
     if (!h->d_idx || !h->d_minus) return fail(PIEHIP_ESTATE, "run: setIndex / setMinusCompareElement not called");
     for (u32 q = 1; q < h->nq; q++)
         if (!h->bq_idx[q] || !h->bq_minus[q]) return fail(PIEHIP_ESTATE, "run: a query of the batch has no index matrix or minus element");
-    if (h->nq > 1 && h->row_events) return fail(PIEHIP_ESTATE, "run: staged uploads take one query per run()");
     HIPCHK(hipSetDevice(h->device));
     const u32 b = h->b;
     h->recs.clear();
@@ -1178,7 +1234,7 @@ int piehip_run_into(piehip_handle h, void *d_results)
         const int qrc = ensure_run_queues(h, ng);
         if (qrc) return qrc;
     }
-    if (h->use_graph && !h->profiling && !h->row_events && h->nq == 1) {
+    if (h->use_graph && !h->profiling && !h->host_results && h->nq == 1) {
         // One graph launch instead of ~13 kernel launches and 2 event operations per queue group: the same two chains, forked
         // from and joined back to the handle's stream inside the graph (so consecutive runs do not overlap each other, which
         // the eager path's lazy join allows).
@@ -1245,6 +1301,7 @@ int piehip_run_into(piehip_handle h, void *d_results)
             h->stream = h->side_streams[g];
             h->wait_before_results = h->inputs_dirty ? nullptr : h->ev_fork;
             enqueue_run_bins(h, b0, nb, (u64 *)d_results);
+            if (h->host_results) HIPCHK(download_rows(h, (const u64 *)d_results, b0, nb));  // this group's slice, on this group's queue
             HIPCHK(hipEventRecord(h->ev_join[g], h->side_streams[g]));
             b0 += nb;
         }
@@ -1253,6 +1310,7 @@ int piehip_run_into(piehip_handle h, void *d_results)
     } else {
         join_pending(h);
         enqueue_run_bins(h, 0, b, (u64 *)d_results);
+        if (h->host_results) HIPCHK(download_rows(h, (const u64 *)d_results, 0, b));
         mark_dirty(h);  // the workspace is now in use on the handle's stream: the queues of a later multi-queue run wait for it
     }
     HIPCHK(hipGetLastError());

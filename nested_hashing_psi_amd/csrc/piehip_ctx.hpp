@@ -68,6 +68,13 @@ struct MulWs {
     u64 *dig = nullptr;  // [nb][L][L][N]
 };
 
+// one query's way in from host memory (piehip_host_buffers_q, piehip_stage_*_q)
+struct QueryStage {
+    u64 *pin_idx = nullptr, *pin_minus = nullptr;  // page-locked staging [K][E][2][L][N], [2][L][N]
+    std::vector<bool> rows;                        // pieces on their way since the staging sequence began
+    bool minus = false;
+};
+
 }  // namespace piehip
 using piehip::u32;
 using piehip::u64;
@@ -89,14 +96,13 @@ struct piehip_ctx {
     hipGraphExec_t gexec = nullptr;
     const void *g_idx = nullptr, *g_minus = nullptr, *g_res = nullptr;
     u32 g_ng = 0;
-    // piehip_run_host: copy queue, one "row landed" event per inner hash function, pinned staging owned by the handle
-    hipStream_t copy_stream = nullptr;
-    std::vector<hipEvent_t> ev_h2d;               // [K]: index-matrix row h (and, for h = 0, the minus element) is in HBM
-    hipEvent_t ev_copy_gate = nullptr, ev_minus_h2d = nullptr;
-    bool stage_open = false, staged_minus = false;  // piehip_stage_*: a query's uploads have begun; which pieces are on their way
-    std::vector<bool> staged_rows;
-    const hipEvent_t *row_events = nullptr;       // set while piehip_run_host enqueues: stage A of row h waits for row_events[h]
-    u64 *pin_idx = nullptr, *pin_minus = nullptr, *pin_res = nullptr;
+    // the host-memory path (piehip_host.cpp): per query of the batch its page-locked staging and which pieces have been staged;
+    // all transfers travel on the handle's own queues (no copy stream: see piehip_host.cpp)
+    piehip::QueryStage qstage[piehip::STAGE_A_MAX_QUERIES];
+    bool stage_open = false;                      // piehip_stage_*: the uploads of the next run()'s queries have begun
+    hipEvent_t ev_up = nullptr;                   // behind this handle's last staged piece (the next upload of the device queues behind it)
+    u64 *host_results = nullptr;                  // set while piehip_run_staged enqueues: every queue group downloads its slice there
+    u64 *pin_res = nullptr;                       // [b][nq][2][L][N]
     size_t pin_idx_words = 0, pin_res_words = 0;
     piehip::DevConsts *d_dc = nullptr;
     u64 *d_tables = nullptr;  // [(M+1)][4][N]
@@ -133,8 +139,13 @@ struct piehip_ctx {
     // above, queries 1 .. nq - 1 are bq_*[q].  Workspace and results hold nq rows per bin layer: [b][nq][..].
     u32 nq = 1;
     u32 mask_div = 1;  // set while run() enqueues a batch: ciphertext row r of the product chain takes mask r / mask_div
+    u32 key_group = 1; // ... and, with per-query EvalMult keys, key r % key_group of d_evkq
     const u64 *bq_idx[piehip::STAGE_A_MAX_QUERIES] = {}, *bq_minus[piehip::STAGE_A_MAX_QUERIES] = {};
     u64 *bq_idx_own[piehip::STAGE_A_MAX_QUERIES] = {}, *bq_minus_own[piehip::STAGE_A_MAX_QUERIES] = {};
+    // piehip_load_relin_key_q: the queries of a batch come from different clients, each with its own EvalMult key.  [evkq_n] keys
+    // [L][2][L][N] one after the other (+ the lane-ordered copy); entries nobody loaded hold the handle's key
+    u64 *d_evkq = nullptr, *d_evkq_sigma = nullptr;
+    u32 evkq_n = 0, evkq_loaded = 0;    // keys the array holds; bit q: query q loaded its own
     // run() workspace
     u64 *d_acc = nullptr;   // [b][K][2][L][N]
     u64 *d_prod = nullptr;  // [b][2][L][N]  (K > 2 only)
@@ -161,6 +172,12 @@ struct piehip_ctx {
 };
 
 namespace piehip {
+
+// the key switch of run() has a key for every query: the handle's, or one per query of the batch (piehip_load_relin_key_q)
+inline bool run_keys_loaded(const piehip_ctx *h)
+{
+    return h->K <= 1 || h->d_evk || (h->d_evkq && h->evkq_n == h->nq && h->evkq_loaded == (1u << h->nq) - 1);
+}
 
 hipEvent_t prof_event(piehip_ctx *h);
 // brackets the launches queued in its scope with HIP events on the handle's current stream when profiling is on
@@ -238,6 +255,9 @@ void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, const u6
 void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const u64 *y, size_t sy, u32 nb, bool relin,
                  const u64 *mask, u64 *out, bool xq_ready = false, bool out_is_result = false);
 int encode_on_device(piehip_ctx *h, const int64_t *d_slots, u32 npt, u32 B, u64 *d_out);
+// device input buffers of query q of the batch (owned copies: the host setters and the staged uploads write them)
+int query_input_buffers(piehip_ctx *h, u32 q, u64 **d_idx, u64 **d_minus);
+void free_host_path(piehip_ctx *h);   // piehip_host.cpp: page-locked staging
 // queues of a run() and the bin layers each takes
 u32 run_queue_count(const piehip_ctx *h);
 int ensure_run_queues(piehip_ctx *h, u32 ng);

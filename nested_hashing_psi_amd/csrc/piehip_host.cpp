@@ -1,101 +1,181 @@
-// piehip_host.cpp -- the host-memory path of a query (include/piehip.h: piehip_host_buffers, piehip_stage_*, piehip_run_staged,
+// piehip_host.cpp -- the host-memory path of a query (include/piehip.h: piehip_host_buffers*, piehip_stage_*, piehip_run_staged,
 // piehip_run_host*): the reference server holds the query as deserialised ciphertexts in host memory when its timer starts
 // (src/Server/FHE/BatchedFHEPSIServer.cpp:94-108); here every piece crosses PCIe from page-locked staging as soon as it exists.
+// A handle that evaluates a batch of nq queries per run() (piehip_set_query_batch) stages every query of the batch the same
+// way -- the queries of a batch are different clients' (.cpp:94-95: one per connection), so their pieces arrive interleaved.
+//
+// Queues.  Everything of a query travels on the handle's OWN queues, in order: the uploads on the handle's stream, the evaluation
+// behind them (run()'s queues fork from that stream), and each queue group's slice of the result list on the queue that computed
+// it, straight behind its last kernel.  No copy stream, no cross-stream event waits.  Rounds 2-3 gave every handle a private copy
+// stream; a rocprofv3 trace of a stream of queries over several query slots (profiles/r04/host_stream_trace.txt) showed why that
+// ran at 0.72-0.86 ms per C3 query where the link's duplex rate allows 0.57: the HIP runtime multiplexes a process's streams
+// onto four hardware queues, a stream's wait for another stream's event is a barrier packet in its hardware queue, and a
+// barrier blocks every later packet of that hardware queue -- also those of the OTHER streams mapped to it.  One slot's "wait for
+// my download" or "wait for my run" stalled another slot's uploads and kernels.  With one in-order chain per handle the slots
+// only meet on the PCIe link and on the CUs.
+//
+// Upload order.  Uploads of different handles that are in flight together share the link, finish together, evaluate together and
+// download together: a stream of queries over several slots falls into lock-step -- every slot uploading, then every slot
+// computing, then every slot downloading, never one direction busy while the other is (same trace).  The queries of a device
+// therefore go up in the order they were staged, one at a time at the full link rate: a staging sequence begins behind the
+// last piece any handle of the device has staged (one event wait per query).  While query i + 1 crosses PCIe, query i
+// evaluates and its results come down.
 #include "piehip_ctx.hpp"
+
+#include <mutex>
 
 using namespace piehip;
 
+namespace {
+std::mutex g_up_mutex;
+std::map<int, hipEvent_t> g_last_up;   // per device: recorded behind the most recently staged piece (the event is its handle's)
+}  // namespace
+
+// the first piece of a staging sequence waits for the uploads staged before it on this device, whichever handle they belong to
+static int upload_turn(piehip_ctx *h)
+{
+    if (!h->ev_up) HIPCHK(hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming));
+    std::lock_guard<std::mutex> lock(g_up_mutex);
+    const hipEvent_t last = g_last_up[h->device];
+    if (last && last != h->ev_up) HIPCHK(hipStreamWaitEvent(h->stream, last, 0));
+    return PIEHIP_OK;
+}
+static int upload_staged(piehip_ctx *h)
+{
+    HIPCHK(hipEventRecord(h->ev_up, h->stream));
+    std::lock_guard<std::mutex> lock(g_up_mutex);
+    g_last_up[h->device] = h->ev_up;
+    return PIEHIP_OK;
+}
+
+namespace piehip {
+
+void free_host_path(piehip_ctx *h)
+{
+    if (h->ev_up) {
+        {
+            std::lock_guard<std::mutex> lock(g_up_mutex);
+            auto it = g_last_up.find(h->device);
+            if (it != g_last_up.end() && it->second == h->ev_up) g_last_up.erase(it);
+        }
+        (void)hipEventDestroy(h->ev_up);
+        h->ev_up = nullptr;
+    }
+    for (QueryStage &s : h->qstage) {
+        if (s.pin_idx) (void)hipHostFree(s.pin_idx);
+        if (s.pin_minus) (void)hipHostFree(s.pin_minus);
+        s.pin_idx = s.pin_minus = nullptr;
+    }
+    if (h->pin_res) (void)hipHostFree(h->pin_res);
+    h->pin_res = nullptr;
+}
+
+}  // namespace piehip
+
+// One run()'s uploads, piece by piece (piehip_stage_*): every piece is one asynchronous copy from host memory on the handle's
+// stream, i.e. behind whatever the handle still has in flight (an earlier run that reads the input buffers included).
+static int stage_begin(piehip_ctx *h, u32 q)
+{
+    if (!h->K || !h->d_db) return fail(PIEHIP_ESTATE, "run: database not loaded");
+    if (q >= h->nq) return fail(PIEHIP_EINVAL, "query index outside the batch (piehip_set_query_batch)");
+    HIPCHK(hipSetDevice(h->device));
+    join_pending(h);
+    mark_dirty(h);
+    if (h->stage_open) return PIEHIP_OK;
+    int rc = upload_turn(h);
+    if (rc) return rc;
+    h->stage_open = true;
+    for (u32 i = 0; i < h->nq; i++) {
+        h->qstage[i].minus = false;
+        h->qstage[i].rows.assign(h->K, false);
+    }
+    return PIEHIP_OK;
+}
+
 extern "C" {
 
-static int host_path_setup(piehip_ctx *h)
+int piehip_host_buffers_q(piehip_handle h, uint32_t q, uint64_t **idx, uint64_t **minus, uint64_t **results)
 {
-    if (h->nq > 1) return fail(PIEHIP_ESTATE, "the host-buffer path takes one query per run() (piehip_set_query_batch(h, 1))");
-    if (!h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-    if (!h->ev_copy_gate) HIPCHK(hipEventCreateWithFlags(&h->ev_copy_gate, hipEventDisableTiming));
-    if (!h->ev_minus_h2d) HIPCHK(hipEventCreateWithFlags(&h->ev_minus_h2d, hipEventDisableTiming));
-    while (h->ev_h2d.size() < h->K) {
-        hipEvent_t e = nullptr;
-        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        h->ev_h2d.push_back(e);
+    NEED_RO(h);
+    if (!h->K) return fail(PIEHIP_ESTATE, "load the database first (the buffer sizes depend on K, E and b)");
+    if (q >= h->nq) return fail(PIEHIP_EINVAL, "query index outside the batch (piehip_set_query_batch)");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t iw = (size_t)h->K * h->E * 2 * h->LN(), rw = (size_t)h->b * h->nq * 2 * h->LN();
+    if (h->pin_idx_words != iw)  // another database shape: every query's index staging goes
+        for (QueryStage &s : h->qstage)
+            if (s.pin_idx) {
+                (void)hipHostFree(s.pin_idx);
+                s.pin_idx = nullptr;
+            }
+    if (h->pin_res && h->pin_res_words != rw) {
+        (void)hipHostFree(h->pin_res);
+        h->pin_res = nullptr;
     }
+    // Portable: one process may drive several devices from the same staging arrays (host/ShardedBatchedFHEHIPPIE.hpp uploads
+    // shard 0's arrays to every device).  Only what the caller asks for: such a shard needs a result array only.
+    QueryStage &s = h->qstage[q];
+    if (idx && !s.pin_idx) HIPCHK(hipHostMalloc((void **)&s.pin_idx, iw * sizeof(u64), hipHostMallocPortable));
+    if (minus && !s.pin_minus) HIPCHK(hipHostMalloc((void **)&s.pin_minus, 2 * h->LN() * sizeof(u64), hipHostMallocPortable));
+    if (results && !h->pin_res) HIPCHK(hipHostMalloc((void **)&h->pin_res, rw * sizeof(u64), hipHostMallocPortable));
+    h->pin_idx_words = iw;
+    h->pin_res_words = rw;
+    // whoever asks for the staging arrays is about to run queries from host memory: create the device-side input buffers and the
+    // run queues now (the offline phase), not inside the first timed query
+    int rc;
+    u64 *di = nullptr, *dm = nullptr;
+    if ((rc = query_input_buffers(h, q, &di, &dm))) return rc;
+    const u32 ng = run_queue_count(h);
+    if (ng > 1 && (rc = ensure_run_queues(h, ng))) return rc;
+    if (idx) *idx = s.pin_idx;
+    if (minus) *minus = s.pin_minus;
+    if (results) *results = h->pin_res;
     return PIEHIP_OK;
 }
 
 int piehip_host_buffers(piehip_handle h, uint64_t **idx, uint64_t **minus, uint64_t **results)
 {
-    NEED_RO(h);
-    if (!h->K) return fail(PIEHIP_ESTATE, "load the database first (the buffer sizes depend on K, E and b)");
-    HIPCHK(hipSetDevice(h->device));
-    const size_t iw = (size_t)h->K * h->E * 2 * h->LN(), rw = (size_t)h->b * 2 * h->LN();
-    if (h->pin_idx && h->pin_idx_words != iw) {
-        (void)hipHostFree(h->pin_idx);
-        h->pin_idx = nullptr;
-    }
-    if (h->pin_res && h->pin_res_words != rw) {
-        (void)hipHostFree(h->pin_res);
-        h->pin_res = nullptr;
-    }
-    if (!h->pin_idx) HIPCHK(hipHostMalloc((void **)&h->pin_idx, iw * sizeof(u64), hipHostMallocDefault));
-    if (!h->pin_minus) HIPCHK(hipHostMalloc((void **)&h->pin_minus, 2 * h->LN() * sizeof(u64), hipHostMallocDefault));
-    if (!h->pin_res) HIPCHK(hipHostMalloc((void **)&h->pin_res, rw * sizeof(u64), hipHostMallocDefault));
-    h->pin_idx_words = iw;
-    h->pin_res_words = rw;
-    // whoever asks for the staging arrays is about to run queries from host memory: create the copy queue, its events and the
-    // run queues now (the offline phase), not inside the first timed query
-    int rc = host_path_setup(h);
-    if (rc) return rc;
-    const u32 ng = run_queue_count(h);
-    if (ng > 1 && (rc = ensure_run_queues(h, ng))) return rc;
-    if (idx) *idx = h->pin_idx;
-    if (minus) *minus = h->pin_minus;
-    if (results) *results = h->pin_res;
-    return PIEHIP_OK;
+    return piehip_host_buffers_q(h, 0, idx, minus, results);
 }
 
-// One query's uploads, piece by piece (piehip_stage_*): the copy queue is gated once behind everything queued so far -- the uploads
-// may not overtake a run that still reads the input buffers -- and every piece is one asynchronous copy from host memory.
-static int stage_begin(piehip_ctx *h)
-{
-    if (!h->K || !h->d_db) return fail(PIEHIP_ESTATE, "run: database not loaded");
-    HIPCHK(hipSetDevice(h->device));
-    if (h->stage_open) return PIEHIP_OK;
-    int rc = host_path_setup(h);
-    if (rc) return rc;
-    const size_t LN = h->LN(), row = (size_t)h->E * 2 * LN;
-    if (!h->d_idx_own && (rc = dev_alloc(&h->d_idx_own, (size_t)h->K * row))) return rc;
-    if (!h->d_minus_own && (rc = dev_alloc(&h->d_minus_own, 2 * LN))) return rc;
-    join_pending(h);
-    HIPCHK(hipEventRecord(h->ev_copy_gate, h->stream));
-    HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_copy_gate, 0));
-    h->stage_open = true;
-    h->staged_minus = false;
-    h->staged_rows.assign(h->K, false);
-    return PIEHIP_OK;
-}
-
-int piehip_stage_minus(piehip_handle h, const uint64_t *minus)
+int piehip_stage_minus_q(piehip_handle h, uint32_t q, const uint64_t *minus)
 {
     if (!h) return fail(PIEHIP_EINVAL, "null handle");
     if (!minus) return fail(PIEHIP_EINVAL, "null input");
-    int rc = stage_begin(h);
+    int rc = stage_begin(h, q);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(h->d_minus_own, minus, 2 * h->LN() * sizeof(u64), hipMemcpyHostToDevice, h->copy_stream));
-    HIPCHK(hipEventRecord(h->ev_minus_h2d, h->copy_stream));
-    h->staged_minus = true;
-    return PIEHIP_OK;
+    u64 *di = nullptr, *dm = nullptr;
+    if ((rc = query_input_buffers(h, q, &di, &dm))) return rc;
+    HIPCHK(hipMemcpyAsync(dm, minus, 2 * h->LN() * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    h->qstage[q].minus = true;
+    return upload_staged(h);
 }
 
-int piehip_stage_index_row(piehip_handle h, uint32_t row, const uint64_t *row_data)
+int piehip_stage_index_row_q(piehip_handle h, uint32_t q, uint32_t row, const uint64_t *row_data)
 {
     if (!h) return fail(PIEHIP_EINVAL, "null handle");
     if (!row_data) return fail(PIEHIP_EINVAL, "null input");
-    int rc = stage_begin(h);
+    int rc = stage_begin(h, q);
     if (rc) return rc;
     if (row >= h->K) return fail(PIEHIP_EINVAL, "stage_index_row: the index matrix has one row per inner hash function");
+    u64 *di = nullptr, *dm = nullptr;
+    if ((rc = query_input_buffers(h, q, &di, &dm))) return rc;
     const size_t words = (size_t)h->E * 2 * h->LN();
-    HIPCHK(hipMemcpyAsync(h->d_idx_own + (size_t)row * words, row_data, words * sizeof(u64), hipMemcpyHostToDevice, h->copy_stream));
-    HIPCHK(hipEventRecord(h->ev_h2d[row], h->copy_stream));
-    h->staged_rows[row] = true;
+    HIPCHK(hipMemcpyAsync(di + (size_t)row * words, row_data, words * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    h->qstage[q].rows[row] = true;
+    return upload_staged(h);
+}
+
+int piehip_stage_minus(piehip_handle h, const uint64_t *minus) { return piehip_stage_minus_q(h, 0, minus); }
+int piehip_stage_index_row(piehip_handle h, uint32_t row, const uint64_t *row_data) { return piehip_stage_index_row_q(h, 0, row, row_data); }
+
+int piehip_stage_reset(piehip_handle h)
+{
+    if (!h) return fail(PIEHIP_EINVAL, "null handle");
+    h->stage_open = false;  // copies already queued still land (in buffers nothing reads until they are staged again)
+    for (QueryStage &s : h->qstage) {
+        s.minus = false;
+        s.rows.assign(s.rows.size(), false);
+    }
     return PIEHIP_OK;
 }
 
@@ -103,53 +183,39 @@ int piehip_run_staged(piehip_handle h, uint64_t *results)
 {
     if (!h) return fail(PIEHIP_EINVAL, "null handle");
     if (!h->K || !h->d_db) return fail(PIEHIP_ESTATE, "run: database not loaded");
-    if (!h->d_evk && h->K > 1) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
-    if (!h->stage_open || !h->staged_minus) return fail(PIEHIP_ESTATE, "run_staged: minus element not staged");
-    for (u32 hf = 0; hf < h->K; hf++)
-        if (!h->staged_rows[hf]) return fail(PIEHIP_ESTATE, "run_staged: index matrix row not staged");
+    if (!run_keys_loaded(h)) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
+    if (!h->stage_open) return fail(PIEHIP_ESTATE, "run_staged: query not staged");
+    const u32 nq = h->nq;
+    for (u32 q = 0; q < nq; q++) {
+        if (!h->qstage[q].minus) return fail(PIEHIP_ESTATE, "run_staged: minus element not staged");
+        for (u32 hf = 0; hf < h->K; hf++)
+            if (!h->qstage[q].rows[hf]) return fail(PIEHIP_ESTATE, "run_staged: index matrix row not staged");
+    }
     HIPCHK(hipSetDevice(h->device));
-    const size_t LN = h->LN();
     h->stage_open = false;
     h->d_idx = h->d_idx_own;
     h->d_minus = h->d_minus_own;
-    // the minus element enters at the end of every stage A launch: the handle's stream (and, through the fork, every queue)
-    // waits for it; row h of the index matrix is waited for by stage A of row h only
-    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_minus_h2d, 0));
+    for (u32 q = 1; q < nq; q++) h->bq_idx[q] = h->bq_idx_own[q], h->bq_minus[q] = h->bq_minus_own[q];
+    // the uploads are on the handle's stream and the run's queues start behind it (the inputs changed); every queue group's slice
+    // of the result list leaves on that group's queue as soon as the group is done
     mark_dirty(h);
-    h->row_events = h->ev_h2d.data();
-    int rc = piehip_run_into(h, h->d_out);
-    h->row_events = nullptr;
-    if (rc) return rc;
-    if (results) {
-        // every queue group's slice of the result list leaves as soon as that group is done
-        if (h->pending_join) {
-            const u32 ng = run_queue_count(h);
-            u32 b0 = 0;
-            for (u32 g = 0; g < ng; g++) {
-                const u32 nb = run_group_size(h->b, ng, g);
-                HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_join[g], 0));
-                HIPCHK(hipMemcpyAsync(results + (size_t)b0 * 2 * LN, h->d_out + (size_t)b0 * 2 * LN, (size_t)nb * 2 * LN * sizeof(u64),
-                                      hipMemcpyDeviceToHost, h->copy_stream));
-                b0 += nb;
-            }
-        } else {
-            HIPCHK(hipEventRecord(h->ev_copy_gate, h->stream));
-            HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_copy_gate, 0));
-            HIPCHK(hipMemcpyAsync(results, h->d_out, (size_t)h->b * 2 * LN * sizeof(u64), hipMemcpyDeviceToHost, h->copy_stream));
-        }
-    }
-    return PIEHIP_OK;
+    h->host_results = results;
+    const int rc = piehip_run_into(h, h->d_out);
+    h->host_results = nullptr;
+    return rc;
 }
 
 int piehip_run_host_async(piehip_handle h, const uint64_t *idx, const uint64_t *minus, uint64_t *results)
 {
     if (!h) return fail(PIEHIP_EINVAL, "null handle");
     if (!idx || !minus) return fail(PIEHIP_EINVAL, "null input");
-    if (h->K && !h->d_evk && h->K > 1) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
-    h->stage_open = false;  // a query of its own: pieces staged earlier and never run are dropped
-    int rc = piehip_stage_minus(h, minus);
+    if (h->K && !run_keys_loaded(h)) return fail(PIEHIP_ESTATE, "run: relinearisation key not loaded");
+    h->stage_open = false;  // queries of its own: pieces staged earlier and never run are dropped
     const size_t row = (size_t)h->E * 2 * h->LN();
-    for (u32 hf = 0; hf < h->K && !rc; hf++) rc = piehip_stage_index_row(h, hf, idx + (size_t)hf * row);
+    int rc = PIEHIP_OK;
+    for (u32 q = 0; q < h->nq && !rc; q++) rc = piehip_stage_minus_q(h, q, minus + (size_t)q * 2 * h->LN());
+    for (u32 q = 0; q < h->nq && !rc; q++)
+        for (u32 hf = 0; hf < h->K && !rc; hf++) rc = piehip_stage_index_row_q(h, q, hf, idx + ((size_t)q * h->K + hf) * row);
     if (rc) {
         h->stage_open = false;
         return rc;
@@ -161,8 +227,7 @@ int piehip_run_host_wait(piehip_handle h)
 {
     if (!h) return fail(PIEHIP_EINVAL, "null handle");
     HIPCHK(hipSetDevice(h->device));
-    if (h->copy_stream) HIPCHK(hipStreamSynchronize(h->copy_stream));
-    join_pending(h);
+    join_pending(h);  // uploads, evaluation and downloads are all behind the handle's stream now
     HIPCHK(hipStreamSynchronize(h->stream));
     return PIEHIP_OK;
 }

@@ -145,6 +145,17 @@ public:
     // run() in two halves: the evaluation and the download of the result list are asynchronous; collect() waits for them
     void enqueue()
     {
+        // whatever happens below, the next query starts from a clean slate: a refused or failed run() must not leave half a
+        // query counted (its pieces would never be staged again)
+        struct Reset {
+            BatchedFHEHIPPIE &o;
+            bool ok = false;
+            ~Reset()
+            {
+                o.clearStaged();
+                if (!ok) piehip_stage_reset(o.cc.handle());
+            }
+        } reset{*this};
         if (minusStaged && rowsStaged == K) {
             PieContext::check(piehip_run_staged(cc.handle(), pinRes));
         } else if (minusStaged || rowsStaged || arrived) {
@@ -154,10 +165,7 @@ public:
             PieContext::check(piehip_run(cc.handle()));
             rerun = true;
         }
-        minusStaged = false;
-        rowsStaged = 0;
-        std::fill(rowCount.begin(), rowCount.end(), 0u);
-        arrived = 0;
+        reset.ok = true;
     }
     void collect()
     {
@@ -189,6 +197,7 @@ public:
             for (uint32_t j = 0; j < E; j++)
                 if (indexMatrix[h][j].limbs.size() != ct) throw std::invalid_argument("ciphertext does not match the context");
         }
+        restartIndex();  // the reference's setter overwrites the matrix (.hpp:40-43): a second call before run() replaces the first
         for (uint32_t h = 0; h < K; h++)
             for (uint32_t j = 0; j < E; j++) {  // one copy, straight into the staging array; row h uploads while row h + 1 is copied
                 std::memcpy(indexStaging(h, j), indexMatrix[h][j].limbs.data(), ct * sizeof(uint64_t));
@@ -199,13 +208,23 @@ public:
     void setMinusCompareElement(LimbCt minusCompareElement)  // .hpp:45-48
     {
         if (minusCompareElement.limbs.size() != ctWords()) throw std::invalid_argument("ciphertext does not match the context");
+        if (minusStaged) drainUploads();  // the previous element may still be crossing PCIe from this very array
         std::memcpy(minusStaging(), minusCompareElement.limbs.data(), ctWords() * sizeof(uint64_t));
         stageMinus();
     }
 
     // ---- zero-copy variant of the two setters, for a deserialiser ------------------------------------------------------------
+    // Call restartIndex() before writing a NEW index matrix over one whose pieces were already handed over and not yet run
+    // (setIndex does): the uploads in flight are waited for and every row is staged afresh.
     uint64_t *indexStaging(uint32_t h, uint32_t j) { return pinIdx + ((size_t)h * E + j) * ctWords(); }  // [2][L][N] of idx[h][j]
     uint64_t *minusStaging() { return pinMinus; }
+    void restartIndex()
+    {
+        if (!arrived && !rowsStaged) return;
+        drainUploads();
+        std::fill(rowCount.begin(), rowCount.end(), 0u);
+        rowsStaged = arrived = 0;
+    }
     // ciphertext (h, j) has been written to indexStaging(h, j); the row's upload starts when its E ciphertexts have arrived
     void stageIndexCiphertext(uint32_t h, uint32_t j)
     {
@@ -232,6 +251,13 @@ protected:
         resultList.resize(b);
         rowCount.assign(K, 0u);
     }
+    void clearStaged()
+    {
+        minusStaged = false;
+        rowsStaged = arrived = 0;
+        std::fill(rowCount.begin(), rowCount.end(), 0u);
+    }
+    void drainUploads() { PieContext::check(piehip_run_host_wait(cc.handle())); }  // the copy queue is idle afterwards
     PieContext &cc;
     uint32_t K = 0, b = 0, E = 0;
     std::vector<LimbCt> resultList;
@@ -243,61 +269,170 @@ protected:
 
 // Several queries per run() (piehip_set_query_batch): a server with clients waiting evaluates their queries together -- stage A
 // then streams the packed database once for the batch, and every later launch carries nq times the ciphertexts.  The reference
-// operator has one query per run() (BatchedFHEHIPPIE.hpp:40-48); this class keeps its call order per query:
-// setMinusCompareElement(q, ..), setIndex(q, ..) for every q < nq, run(), getResultList(q).  Every query's result list is
-// bit-identical to what BatchedFHEHIPPIE::run() gives for that query alone.
+// operator has one query per run() (BatchedFHEHIPPIE.hpp:40-48) and the reference server one client per process
+// (BatchedFHEPSIServer.cpp:94-95); this class keeps the operator's call order per query:
+//     setEvalMultKey(q, ..) once per client; then per batch setMinusCompareElement(q, ..), setIndex(q, ..) for every q < nq,
+//     run(), getResultList(q).
+// Every query's result list is bit-identical to what BatchedFHEHIPPIE::run() gives for that query alone under that client's key.
+// Host path as in BatchedFHEHIPPIE: every query has page-locked staging of its own (piehip_host_buffers_q), a piece starts its
+// upload when it is complete (piehip_stage_*_q; pieces of different queries in any order -- the clients' messages interleave),
+// run() is piehip_run_staged + wait, and the result lists are read from the page-locked result array [b][nq].
 // `cryptoContext` is a context of its own (same parameters as `database`'s, its own stream and workspace) attached to
-// `database`'s key and packed table; `database` must outlive this object.
+// `database`'s packed table; `database` must outlive this object.
 class BatchedFHEHIPPIEQueryBatch {
 public:
     BatchedFHEHIPPIEQueryBatch(PieContext &cryptoContext, const BatchedFHEHIPPIE &database, uint32_t queriesPerRun)
         : cc(cryptoContext), K(database.K), b(database.b), E(database.E), nq(queriesPerRun)
     {
         PieContext::check(piehip_attach_database(cc.handle(), database.cc.handle()));
-        PieContext::check(piehip_set_query_batch(cc.handle(), nq));
-        results.resize((size_t)b * nq * ctWords());
-        lists.assign(nq, std::vector<LimbCt>(b));
-        row.resize((size_t)K * E * ctWords());
+        init();
     }
     uint32_t queriesPerRun() const { return nq; }
+
+    // the EvalMult key of query q's client, evk[L][2][L][N] (BatchedFHEPSIServer.cpp:45-49); queries without one use the key
+    // of the context the database lives on
+    void setEvalMultKey(uint32_t q, const uint64_t *evk) { PieContext::check(piehip_load_relin_key_q(cc.handle(), q, evk)); }
 
     void setIndex(uint32_t q, std::vector<std::vector<LimbCt>> &&indexMatrix)  // [K][E] ciphertexts of query q
     {
         const size_t ct = ctWords();
+        checkQuery(q);
         if (indexMatrix.size() != K) throw std::invalid_argument("index matrix must have one row per inner hash function");
         for (uint32_t h = 0; h < K; h++) {
             if (indexMatrix[h].size() != E) throw std::invalid_argument("index matrix row length must be eachCuckooTableSize");
-            for (uint32_t j = 0; j < E; j++) {
+            for (uint32_t j = 0; j < E; j++)
                 if (indexMatrix[h][j].limbs.size() != ct) throw std::invalid_argument("ciphertext does not match the context");
-                std::memcpy(&row[((size_t)h * E + j) * ct], indexMatrix[h][j].limbs.data(), ct * sizeof(uint64_t));
-            }
         }
-        PieContext::check(piehip_set_index_q(cc.handle(), q, row.data()));
+        restartIndex(q);
+        for (uint32_t h = 0; h < K; h++)
+            for (uint32_t j = 0; j < E; j++) {
+                std::memcpy(indexStaging(q, h, j), indexMatrix[h][j].limbs.data(), ct * sizeof(uint64_t));
+                stageIndexCiphertext(q, h, j);
+            }
     }
     void setMinusCompareElement(uint32_t q, const LimbCt &minusCompareElement)
     {
+        checkQuery(q);
         if (minusCompareElement.limbs.size() != ctWords()) throw std::invalid_argument("ciphertext does not match the context");
-        PieContext::check(piehip_set_minus_q(cc.handle(), q, minusCompareElement.limbs.data()));
+        if (st[q].minusStaged) drainUploads();
+        std::memcpy(minusStaging(q), minusCompareElement.limbs.data(), ctWords() * sizeof(uint64_t));
+        stageMinus(q);
     }
+    // zero-copy variant for a deserialiser (see BatchedFHEHIPPIE)
+    uint64_t *indexStaging(uint32_t q, uint32_t h, uint32_t j) { return st[q].pinIdx + ((size_t)h * E + j) * ctWords(); }
+    uint64_t *minusStaging(uint32_t q) { return st[q].pinMinus; }
+    void restartIndex(uint32_t q)
+    {
+        checkQuery(q);
+        if (!st[q].arrived && !st[q].rowsStaged) return;
+        drainUploads();
+        std::fill(st[q].rowCount.begin(), st[q].rowCount.end(), 0u);
+        st[q].rowsStaged = st[q].arrived = 0;
+    }
+    void stageIndexCiphertext(uint32_t q, uint32_t h, uint32_t j)
+    {
+        checkQuery(q);
+        if (h >= K || j >= E) throw std::invalid_argument("index matrix position out of range");
+        st[q].arrived++;
+        if (++st[q].rowCount[h] == E) {
+            PieContext::check(piehip_stage_index_row_q(cc.handle(), q, h, indexStaging(q, h, 0)));
+            st[q].rowsStaged++;
+        }
+    }
+    void stageMinus(uint32_t q)
+    {
+        checkQuery(q);
+        PieContext::check(piehip_stage_minus_q(cc.handle(), q, st[q].pinMinus));
+        st[q].minusStaged = true;
+    }
+
     void run()  // BatchedFHEHIPPIE.cpp:88-129 for every query of the batch
     {
-        PieContext::check(piehip_run(cc.handle()));
-        PieContext::check(piehip_get_results(cc.handle(), results.data()));  // rows [bin layer][query]
-        const size_t ct = ctWords();
-        for (uint32_t q = 0; q < nq; q++)
-            for (uint32_t i = 0; i < b; i++) {
-                const uint64_t *src = &results[((size_t)i * nq + q) * ct];
-                lists[q][i].limbs.assign(src, src + ct);
-            }
+        enqueue();
+        collect();
     }
-    std::vector<LimbCt> &getResultList(uint32_t q) { return lists.at(q); }  // the b result ciphertexts of query q
+    void enqueue()
+    {
+        struct Reset {
+            BatchedFHEHIPPIEQueryBatch &o;
+            bool ok = false;
+            ~Reset()
+            {
+                for (auto &s : o.st) {
+                    s.minusStaged = false;
+                    s.rowsStaged = s.arrived = 0;
+                    std::fill(s.rowCount.begin(), s.rowCount.end(), 0u);
+                }
+                if (!ok) piehip_stage_reset(o.cc.handle());
+            }
+        } reset{*this};
+        uint32_t complete = 0, touched = 0;
+        for (const auto &s : st) {
+            complete += (s.minusStaged && s.rowsStaged == K) ? 1u : 0u;
+            touched += (s.minusStaged || s.rowsStaged || s.arrived) ? 1u : 0u;
+        }
+        if (complete == nq) {
+            PieContext::check(piehip_run_staged(cc.handle(), pinRes));
+        } else if (touched) {
+            throw std::runtime_error("run: setMinusCompareElement and setIndex of every query of the batch must precede run()");
+        } else {
+            PieContext::check(piehip_run(cc.handle()));  // the previous batch again
+            rerun = true;
+        }
+        reset.ok = true;
+    }
+    void collect()
+    {
+        if (rerun) PieContext::check(piehip_get_results(cc.handle(), pinRes));
+        else PieContext::check(piehip_run_host_wait(cc.handle()));
+        rerun = false;
+        std::fill(listStale.begin(), listStale.end(), true);
+    }
+    // the b result ciphertexts of query q (materialised on the first call after a run(); resultTowers reads them in place)
+    std::vector<LimbCt> &getResultList(uint32_t q)
+    {
+        checkQuery(q);
+        if (listStale[q]) {
+            const size_t ct = ctWords();
+            for (uint32_t i = 0; i < b; i++) lists[q][i].limbs.assign(resultTowers(q, i), resultTowers(q, i) + ct);
+            listStale[q] = false;
+        }
+        return lists[q];
+    }
+    const uint64_t *resultTowers(uint32_t q, uint32_t i) const { return pinRes + ((size_t)i * nq + q) * ctWords(); }  // rows [bin layer][query]
 
 private:
+    struct QueryState {
+        uint64_t *pinIdx = nullptr, *pinMinus = nullptr;
+        std::vector<uint32_t> rowCount;
+        uint32_t rowsStaged = 0, arrived = 0;
+        bool minusStaged = false;
+    };
+    void init()
+    {
+        if (nq < 1) throw std::invalid_argument("at least one query per run()");
+        PieContext::check(piehip_set_query_batch(cc.handle(), nq));
+        st.resize(nq);
+        for (uint32_t q = 0; q < nq; q++) {
+            PieContext::check(piehip_host_buffers_q(cc.handle(), q, &st[q].pinIdx, &st[q].pinMinus, &pinRes));
+            st[q].rowCount.assign(K, 0u);
+        }
+        lists.assign(nq, std::vector<LimbCt>(b));
+        listStale.assign(nq, false);
+    }
+    void checkQuery(uint32_t q) const
+    {
+        if (q >= nq) throw std::invalid_argument("query index outside the batch");
+    }
+    void drainUploads() { PieContext::check(piehip_run_host_wait(cc.handle())); }
     size_t ctWords() const { return 2 * (size_t)cc.towers() * cc.ringDimension(); }
     PieContext &cc;
     uint32_t K, b, E, nq;
-    std::vector<uint64_t> results, row;
+    std::vector<QueryState> st;
+    uint64_t *pinRes = nullptr;  // [b][nq][2][L][N], page-locked, owned by the library
     std::vector<std::vector<LimbCt>> lists;
+    std::vector<bool> listStale;
+    bool rerun = false;
 };
 
 }  // namespace piehip

@@ -54,20 +54,36 @@ public:
         }
         resultList.resize(b);
         pinRes.resize(G);
-        for (uint32_t g = 0; g < G; g++) {
-            uint64_t *pi = nullptr, *pm = nullptr;
-            PieContext::check(piehip_host_buffers(ccs[g]->handle(), &pi, &pm, &pinRes[g]));
-            if (g == 0) pinIdx = pi, pinMinus = pm;
-        }
+        // the query is staged once, in the first shard's page-locked arrays (portable: every device uploads from them); the other
+        // shards pin a result array only
+        PieContext::check(piehip_host_buffers(ccs[0]->handle(), &pinIdx, &pinMinus, &pinRes[0]));
+        for (uint32_t g = 1; g < G; g++) PieContext::check(piehip_host_buffers(ccs[g]->handle(), nullptr, nullptr, &pinRes[g]));
     }
 
     void run()  // BatchedFHEHIPPIE.cpp:88-129 on every shard
     {
-        if (!minusStaged || rowsStaged != K) throw std::runtime_error("run: setMinusCompareElement and setIndex must both precede run()");
-        for (size_t g = 0; g < slices.size(); g++) PieContext::check(piehip_run_staged(ccs[g]->handle(), pinRes[g]));  // all devices busy
-        for (size_t g = 0; g < slices.size(); g++) PieContext::check(piehip_run_host_wait(ccs[g]->handle()));
-        minusStaged = false;
-        rowsStaged = 0;
+        struct Reset {  // a refused or failed run() leaves no half-staged query behind on any shard
+            ShardedBatchedFHEHIPPIE &o;
+            bool ok = false;
+            ~Reset()
+            {
+                o.minusStaged = false;
+                o.rowsStaged = 0;
+                if (!ok)
+                    for (size_t g = 0; g < o.slices.size(); g++) piehip_stage_reset(o.ccs[g]->handle());
+            }
+        } reset{*this};
+        if (minusStaged && rowsStaged == K) {
+            for (size_t g = 0; g < slices.size(); g++) PieContext::check(piehip_run_staged(ccs[g]->handle(), pinRes[g]));  // all devices busy
+            for (size_t g = 0; g < slices.size(); g++) PieContext::check(piehip_run_host_wait(ccs[g]->handle()));
+        } else if (minusStaged || rowsStaged) {
+            throw std::runtime_error("run: setMinusCompareElement and setIndex must both precede run()");
+        } else {
+            // nothing set since the last run(): the previous query again, as the reference operator (and BatchedFHEHIPPIE) would
+            for (size_t g = 0; g < slices.size(); g++) PieContext::check(piehip_run(ccs[g]->handle()));
+            for (size_t g = 0; g < slices.size(); g++) PieContext::check(piehip_get_results(ccs[g]->handle(), pinRes[g]));
+        }
+        reset.ok = true;
         listStale = true;
     }
 
@@ -94,6 +110,7 @@ public:
             for (uint32_t j = 0; j < E; j++)
                 if (indexMatrix[h][j].limbs.size() != ct) throw std::invalid_argument("ciphertext does not match the context");
         }
+        if (rowsStaged) drainUploads();  // a second matrix before run() replaces the first: its uploads read these very arrays
         for (uint32_t h = 0; h < K; h++) {
             uint64_t *row = pinIdx + (size_t)h * E * ct;
             for (uint32_t j = 0; j < E; j++) std::memcpy(row + (size_t)j * ct, indexMatrix[h][j].limbs.data(), ct * sizeof(uint64_t));
@@ -106,6 +123,7 @@ public:
     void setMinusCompareElement(LimbCt minusCompareElement)  // .hpp:45-48
     {
         if (minusCompareElement.limbs.size() != ctWords()) throw std::invalid_argument("ciphertext does not match the context");
+        if (minusStaged) drainUploads();
         std::memcpy(pinMinus, minusCompareElement.limbs.data(), ctWords() * sizeof(uint64_t));
         for (size_t g = 0; g < slices.size(); g++) PieContext::check(piehip_stage_minus(ccs[g]->handle(), pinMinus));
         minusStaged = true;
@@ -118,6 +136,10 @@ public:
 
 private:
     size_t ctWords() const { return 2 * (size_t)ccs[0]->towers() * ccs[0]->ringDimension(); }
+    void drainUploads()
+    {
+        for (size_t g = 0; g < slices.size(); g++) PieContext::check(piehip_run_host_wait(ccs[g]->handle()));
+    }
     std::vector<PieContext *> ccs;
     std::vector<Slice> slices;
     uint32_t K = 0, b = 0, E = 0;

@@ -106,15 +106,24 @@ inline void checkCanonical(const uint64_t *limbs, size_t nlimbs, uint32_t L, uin
 // Unpacks straight into caller memory (e.g. the page-locked staging array the upload starts from): dst[count][2][L][N] must
 // hold `expect` ciphertexts.  Throws if the message does not describe [expect][2][L][N] or (moduli != null: q_0..q_{L-1}) a
 // residue is not canonical.
-inline void unpackCiphertextsInto(const std::vector<uint8_t> &msg, uint32_t L, uint32_t N, uint64_t *dst, uint32_t expect,
-                                  const uint64_t *moduli = nullptr)
+// header of a ciphertext message, validated against the context and the message length BEFORE anything is sized by it (the
+// count comes from the other party)
+inline LimbHeader checkedHeader(const std::vector<uint8_t> &msg, uint32_t L, uint32_t N)
 {
     if (msg.size() < sizeof(LimbHeader)) throw std::invalid_argument("short ciphertext message");
     LimbHeader h;
     std::memcpy(&h, msg.data(), sizeof(h));
-    if (h.magic != 0x48454950u || h.L != L || h.N != N || h.count != expect) throw std::invalid_argument("ciphertext message does not match the context");
+    if (h.magic != 0x48454950u || h.L != L || h.N != N) throw std::invalid_argument("ciphertext message does not match the context");
+    const size_t per_ct = (size_t)2 * L * N * sizeof(uint64_t), body = msg.size() - sizeof(LimbHeader);
+    if (per_ct == 0 || body % per_ct != 0 || body / per_ct != h.count) throw std::invalid_argument("ciphertext message length mismatch");
+    return h;
+}
+inline void unpackCiphertextsInto(const std::vector<uint8_t> &msg, uint32_t L, uint32_t N, uint64_t *dst, uint32_t expect,
+                                  const uint64_t *moduli = nullptr)
+{
+    const LimbHeader h = checkedHeader(msg, L, N);
+    if (h.count != expect) throw std::invalid_argument("ciphertext message does not match the context");
     const size_t words = (size_t)h.count * 2 * L * N;
-    if (msg.size() != sizeof(LimbHeader) + words * sizeof(uint64_t)) throw std::invalid_argument("ciphertext message length mismatch");
     std::memcpy(dst, msg.data() + sizeof(h), words * sizeof(uint64_t));
     if (moduli) checkCanonical(dst, (size_t)h.count * 2 * L, L, N, moduli, "ciphertext");
 }
@@ -122,9 +131,7 @@ inline void unpackCiphertextsInto(const std::vector<uint8_t> &msg, uint32_t L, u
 inline uint32_t unpackCiphertexts(const std::vector<uint8_t> &msg, uint32_t L, uint32_t N, std::vector<uint64_t> &limbs,
                                   const uint64_t *moduli = nullptr)
 {
-    if (msg.size() < sizeof(LimbHeader)) throw std::invalid_argument("short ciphertext message");
-    LimbHeader h;
-    std::memcpy(&h, msg.data(), sizeof(h));
+    const LimbHeader h = checkedHeader(msg, L, N);   // the count is bounded by the message that actually arrived
     limbs.resize((size_t)h.count * 2 * L * N);
     unpackCiphertextsInto(msg, L, N, limbs.data(), h.count, moduli);
     return h.count;

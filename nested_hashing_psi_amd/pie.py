@@ -156,10 +156,15 @@ class PieContext:
         _check(lib().piehip_base_convert(self._h, which, ap, npoly, out.ctypes.data_as(u64p)))
         return out
 
-    def load_relin_key(self, evk):
+    def load_relin_key(self, evk, query=None):
+        """InsertEvalMultKey.  query=q: the key of query q's client in a batch (piehip_load_relin_key_q; the queries of a batch are
+        different clients', each with its own key -- BatchedFHEPSIServer.cpp:45-49); queries without one use the context's key."""
         a, ap = _u64(evk)
         assert a.shape == (self.L, 2, self.L, self.N)
-        _check(lib().piehip_load_relin_key(self._h, ap))
+        if query is None:
+            _check(lib().piehip_load_relin_key(self._h, ap))
+        else:
+            _check(lib().piehip_load_relin_key_q(self._h, int(query), ap))
 
     def rotation_galois(self, index):
         """Galois element 5^index mod 2N of the row rotation by `index` (EvalAtIndex convention: > 0 rotates left)"""
@@ -335,25 +340,36 @@ class BatchedFHEHIPPIE:
         if sync:
             _check(lib().piehip_sync(self.cc._h))
 
-    def hostBuffers(self):
-        """page-locked numpy views (index matrix [K][E][2][L][N], minus element [2][L][N], result list [b][2][L][N]) owned by the
+    def _res_shape(self):
+        nq = self.nq
+        return (self.b, 2, self.cc.L, self.cc.N) if nq == 1 else (self.b, nq, 2, self.cc.L, self.cc.N)
+
+    def hostBuffers(self, query=0):
+        """page-locked numpy views (index matrix [K][E][2][L][N] and minus element [2][L][N] of query `query` of the batch, and the
+        operator's result list [b][2][L][N] -- [b][nq][2][L][N] for a batch, the same array for every query) owned by the
         library: a deserialiser that writes the towers straight into them saves the staging copy of the upload"""
         pi, pm, pr = u64p(), u64p(), u64p()
-        _check(lib().piehip_host_buffers(self.cc._h, C.byref(pi), C.byref(pm), C.byref(pr)))
+        _check(lib().piehip_host_buffers_q(self.cc._h, int(query), C.byref(pi), C.byref(pm), C.byref(pr)))
         L, N = self.cc.L, self.cc.N
         mk = lambda ptr, shape: np.ctypeslib.as_array(ptr, shape=shape)
-        return mk(pi, (self.K, self.E, 2, L, N)), mk(pm, (2, L, N)), mk(pr, (self.b, 2, L, N))
+        return mk(pi, (self.K, self.E, 2, L, N)), mk(pm, (2, L, N)), mk(pr, self._res_shape())
+
+    def _in_shapes(self):
+        nq = self.nq
+        pre = () if nq == 1 else (nq,)
+        return pre + (self.K, self.E, 2, self.cc.L, self.cc.N), pre + (2, self.cc.L, self.cc.N)
 
     def runHost(self, indexMatrix, minusCompareElement, results=None):
         """setMinusCompareElement + setIndex + run + getResultList in one pipelined call (piehip_run_host): the query is in host
-        memory, row h of the index matrix uploads while stage A of row h - 1 runs, results download per queue group"""
+        memory, row h of the index matrix uploads while stage A of row h - 1 runs, results download per queue group.
+        A batch of nq queries: indexMatrix [nq][K][E] ciphertexts, minusCompareElement [nq], results [b][nq]."""
         a, ap = _u64(indexMatrix)
         m, mp = _u64(minusCompareElement)
-        if a.shape != (self.K, self.E, 2, self.cc.L, self.cc.N) or m.shape != (2, self.cc.L, self.cc.N):
-            raise ValueError("index matrix must be [K][E] ciphertexts, the minus element one ciphertext")
+        if (a.shape, m.shape) != self._in_shapes():
+            raise ValueError("index matrix must be [K][E] ciphertexts, the minus element one ciphertext (per query of the batch)")
         if results is None:
-            if getattr(self, "_results", None) is None:
-                self._results = np.zeros((self.b, 2, self.cc.L, self.cc.N), dtype=np.uint64)
+            if getattr(self, "_results", None) is None or self._results.shape != self._res_shape():
+                self._results = np.zeros(self._res_shape(), dtype=np.uint64)
             results = self._results
         _check(lib().piehip_run_host(self.cc._h, ap, mp, results.ctypes.data_as(u64p)))
         return results
@@ -364,28 +380,32 @@ class BatchedFHEHIPPIE:
         if indexMatrix.dtype != np.uint64 or not indexMatrix.flags.c_contiguous or minusCompareElement.dtype != np.uint64 \
                 or not minusCompareElement.flags.c_contiguous or results.dtype != np.uint64 or not results.flags.c_contiguous:
             raise ValueError("runHostAsync needs contiguous uint64 arrays (no temporary copies may be taken)")
-        if indexMatrix.shape != (self.K, self.E, 2, self.cc.L, self.cc.N) or minusCompareElement.shape != (2, self.cc.L, self.cc.N) \
-                or results.shape != (self.b, 2, self.cc.L, self.cc.N):
+        if (indexMatrix.shape, minusCompareElement.shape) != self._in_shapes() or results.shape != self._res_shape():
             raise ValueError("index matrix must be [K][E] ciphertexts, the minus element one ciphertext, results [b] ciphertexts")
         _check(lib().piehip_run_host_async(self.cc._h, indexMatrix.ctypes.data_as(u64p), minusCompareElement.ctypes.data_as(u64p),
                                            results.ctypes.data_as(u64p)))
 
-    def stageMinus(self, minusCompareElement):
-        """start the upload of the minus element (piehip_stage_minus); the array must stay untouched until waitHost()"""
+    def stageMinus(self, minusCompareElement, query=0):
+        """start the upload of the minus element of query `query` (piehip_stage_minus_q); the array must stay untouched until waitHost()"""
         if minusCompareElement.dtype != np.uint64 or not minusCompareElement.flags.c_contiguous or minusCompareElement.shape != (2, self.cc.L, self.cc.N):
             raise ValueError("the minus element is one contiguous uint64 ciphertext")
-        _check(lib().piehip_stage_minus(self.cc._h, minusCompareElement.ctypes.data_as(u64p)))
+        _check(lib().piehip_stage_minus_q(self.cc._h, int(query), minusCompareElement.ctypes.data_as(u64p)))
 
-    def stageIndexRow(self, row, rowCiphertexts):
-        """start the upload of row `row` of the index matrix, [E][2][L][N] (piehip_stage_index_row)"""
+    def stageIndexRow(self, row, rowCiphertexts, query=0):
+        """start the upload of row `row` of query `query`'s index matrix, [E][2][L][N] (piehip_stage_index_row_q)"""
         if rowCiphertexts.dtype != np.uint64 or not rowCiphertexts.flags.c_contiguous or rowCiphertexts.shape != (self.E, 2, self.cc.L, self.cc.N):
             raise ValueError("an index matrix row is E contiguous uint64 ciphertexts")
-        _check(lib().piehip_stage_index_row(self.cc._h, int(row), rowCiphertexts.ctypes.data_as(u64p)))
+        _check(lib().piehip_stage_index_row_q(self.cc._h, int(query), int(row), rowCiphertexts.ctypes.data_as(u64p)))
+
+    def stageReset(self):
+        """drop a partial staging sequence (piehip_stage_reset)"""
+        _check(lib().piehip_stage_reset(self.cc._h))
 
     def runStaged(self, results):
-        """evaluate the staged query and queue the download of the result list (piehip_run_staged); waitHost() completes it"""
-        if results.dtype != np.uint64 or not results.flags.c_contiguous or results.shape != (self.b, 2, self.cc.L, self.cc.N):
-            raise ValueError("results must be [b] contiguous uint64 ciphertexts")
+        """evaluate the staged queries and queue the download of the result list (piehip_run_staged); waitHost() completes it.
+        results: [b][2][L][N], or [b][nq][2][L][N] for a batch (the library's row order: the nq results of a bin layer adjacent)"""
+        if results.dtype != np.uint64 or not results.flags.c_contiguous or results.shape != self._res_shape():
+            raise ValueError("results must be [b] ([b][nq] for a batch) contiguous uint64 ciphertexts")
         _check(lib().piehip_run_staged(self.cc._h, results.ctypes.data_as(u64p)))
 
     def waitHost(self):

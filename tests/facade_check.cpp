@@ -41,6 +41,43 @@ int main()
         pie.run();
         std::printf("facade ok: %zu result ciphertexts\n", pie.getResultList().size());
         {
+            // the reference's setters overwrite (BatchedFHEHIPPIE.hpp:40-48): setIndex(A); setIndex(B); run() evaluates B, and a
+            // run() that was refused (only half a query set) leaves the operator usable
+            const std::vector<LimbCt> first = pie.getResultList();
+            auto matrix = [&](uint64_t v) {
+                std::vector<std::vector<LimbCt>> m(2, std::vector<LimbCt>(3));
+                for (auto &row : m)
+                    for (auto &c : row) c.limbs.assign(ct, v);
+                return m;
+            };
+            LimbCt junk;
+            junk.limbs.assign(ct, 11);
+            pie.setMinusCompareElement(junk);
+            pie.setMinusCompareElement(minus);   // replaces junk
+            pie.setIndex(matrix(9));
+            pie.setIndex(matrix(5));             // replaces the matrix of nines
+            pie.run();
+            for (size_t i = 0; i < first.size(); i++)
+                if (pie.getResultList()[i].limbs != first[i].limbs) return 8;
+            pie.setIndex(matrix(9));
+            bool refused = false;
+            try {
+                pie.run();  // no minus element for this query
+            } catch (const std::runtime_error &) {
+                refused = true;
+            }
+            if (!refused) return 9;
+            pie.setMinusCompareElement(minus);
+            pie.setIndex(matrix(5));
+            pie.run();
+            for (size_t i = 0; i < first.size(); i++)
+                if (pie.getResultList()[i].limbs != first[i].limbs) return 10;
+            pie.run();  // nothing set since: the same query again
+            for (size_t i = 0; i < first.size(); i++)
+                if (pie.getResultList()[i].limbs != first[i].limbs) return 11;
+            std::printf("setter overwrite / refused run ok\n");
+        }
+        {
             // a second query slot on the same database: the same query gives the same result list, evaluated concurrently
             PieContext cc2(1024, 2, 65537);
             BatchedFHEHIPPIE slot(cc2, pie);
@@ -58,30 +95,42 @@ int main()
             std::printf("query slot ok\n");
         }
         {
-            // three queries per run() on the same database: each result list equals the single-query operator's
-            PieContext cc3(1024, 2, 65537);
-            BatchedFHEHIPPIEQueryBatch batch(cc3, pie, 3);
+            // three queries per run() on the same database, every one from a client with its own EvalMult key: each result list
+            // equals the single-query operator's under that key
             std::vector<std::vector<LimbCt>> want;
-            for (uint32_t q = 0; q < 3; q++) {
-                LimbCt mq;
-                mq.limbs.assign(ct, 3 + q);
-                std::vector<std::vector<LimbCt>> iq(2, std::vector<LimbCt>(3)), iq2(2, std::vector<LimbCt>(3));
+            std::vector<std::vector<uint64_t>> keys;
+            std::vector<LimbCt> minusOf(3);
+            auto matrixOf = [&](uint32_t q) {
+                std::vector<std::vector<LimbCt>> m(2, std::vector<LimbCt>(3));
                 for (uint32_t h = 0; h < 2; h++)
-                    for (uint32_t j = 0; j < 3; j++) {
-                        iq[h][j].limbs.assign(ct, 5 + 7 * q + h + 2 * j);
-                        iq2[h][j] = iq[h][j];
-                    }
-                pie.setMinusCompareElement(mq);
-                pie.setIndex(std::move(iq));
+                    for (uint32_t j = 0; j < 3; j++) m[h][j].limbs.assign(ct, 5 + 7 * q + h + 2 * j);
+                return m;
+            };
+            for (uint32_t q = 0; q < 3; q++) {   // what each client would get from an operator of its own
+                keys.emplace_back(2 * 2 * 2 * 1024, 1 + 5 * q);
+                cc.setEvalMultKey(keys[q].data());
+                minusOf[q].limbs.assign(ct, 3 + q);
+                pie.setMinusCompareElement(minusOf[q]);
+                pie.setIndex(matrixOf(q));
                 pie.run();
                 want.push_back(pie.getResultList());
-                batch.setMinusCompareElement(q, mq);
-                batch.setIndex(q, std::move(iq2));
+            }
+            cc.setEvalMultKey(evk.data());
+            PieContext cc3(1024, 2, 65537);
+            BatchedFHEHIPPIEQueryBatch batch(cc3, pie, 3);
+            for (uint32_t q = 0; q < 3; q++) {
+                batch.setEvalMultKey(q, keys[q].data());
+                batch.setMinusCompareElement(q, minusOf[q]);
+                batch.setIndex(q, matrixOf(q));
             }
             batch.run();
             for (uint32_t q = 0; q < 3; q++)
                 for (size_t i = 0; i < want[q].size(); i++)
                     if (batch.getResultList(q)[i].limbs != want[q][i].limbs) return 6;
+            batch.run();  // the same batch again
+            for (uint32_t q = 0; q < 3; q++)
+                for (size_t i = 0; i < want[q].size(); i++)
+                    if (batch.getResultList(q)[i].limbs != want[q][i].limbs) return 12;
             bool refused = false;
             try {
                 batch.setMinusCompareElement(3, minus);
@@ -89,6 +138,14 @@ int main()
                 refused = true;
             }
             if (!refused) return 7;
+            refused = false;
+            batch.setMinusCompareElement(1, minus);
+            try {
+                batch.run();  // one query of the batch half set
+            } catch (const std::runtime_error &) {
+                refused = true;
+            }
+            if (!refused) return 13;
             std::printf("query batch ok\n");
         }
         // the rotation-based sibling (FHEHIPPIE.hpp): argument checks, then the reference call order

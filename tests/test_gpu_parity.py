@@ -700,8 +700,8 @@ def test_caller_supplied_moduli(ob, pie, N, L, t, below, what):
 ])
 def test_query_batches(ob, pie, N, L, t, K, E, b, nqs):
     """piehip_set_query_batch: run() over nq queries at once.  Every query's ciphertexts equal the oracle's for that query alone
-    (random limbs), whatever the batch size, the queue count and the order the inputs were set in; the host-buffer path is
-    refused in batch mode and works again after returning to one query per run()."""
+    (random limbs), whatever the batch size, the queue count and the order the inputs were set in (the host-memory path of a
+    batch: test_staged_query_batches)."""
     import torch
     o = ob.Oracle(N, L, t)
     cc = pie.PieContext(N, L, t)
@@ -739,8 +739,6 @@ def test_query_batches(ob, pie, N, L, t, K, E, b, nqs):
             assert got.shape == (nq, b, 2, L, N)
             for i in range(nq):
                 assert (got[i] == want[i]).all(), "query %d of a batch of %d" % (i, nq)
-        with pytest.raises(RuntimeError):
-            op.hostBuffers()
     op.setQueryBatch(1)
     idx, minus = queries[1]
     assert (op.runHost(idx, minus) == want[1]).all()
@@ -868,6 +866,84 @@ def test_staged_query_upload(ob, pie):
     cc.close()
 
 
+@pytest.mark.parametrize("N,L,t,K,E,b,nq", [
+    (4096, 2, T16, 2, 4, 5, 3),        # one queue
+    (16384, 4, T32, 2, 3, 9, 2),       # the headline ring, two queues (5 + 4 layers): results leave per queue group
+    (2048, 3, T32, 3, 5, 4, 4),        # K = 3: three rows per query, two chained products
+    (16384, 4, T32, 2, 14, 3, 3),      # E = 14 as at C3, batch of three
+])
+def test_staged_query_batches(ob, pie, N, L, t, K, E, b, nq):
+    """The host-memory path of a query batch -- what a server with nq clients connected calls (BatchedFHEPSIServer.cpp:94-108 per
+    client): every query has its own page-locked staging (piehip_host_buffers_q), its pieces are staged in whatever order the
+    clients' messages arrive (piehip_stage_minus_q / piehip_stage_index_row_q), run_staged evaluates the batch and the result list
+    [b][nq] comes back in host memory.  Every client has its OWN EvalMult key (piehip_load_relin_key_q): query q's results equal
+    the oracle's run() of that query alone under key q.  Also: a missing piece is a call-order error, a piece staged twice is
+    replaced, stage_reset drops a partial sequence, and piehip_run_host takes the batch in one call."""
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(1000 * nq + N + b)
+    q = cc.q
+    db, masks = rand_limbs(rng, q, (K, b, E), N), rand_limbs(rng, q, (b,), N)
+    keys = [rand_limbs(rng, q, (L, 2), N) for _ in range(nq)]
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    op.setQueryBatch(nq)
+    for i in range(nq):
+        cc.load_relin_key(keys[i], query=i)
+    with pytest.raises(ValueError):
+        cc.load_relin_key(keys[0], query=nq)
+    bufs = [op.hostBuffers(query=i) for i in range(nq)]
+    pr = bufs[0][2]
+    assert pr.shape == (b, nq, 2, L, N) and all(bf[2].ctypes.data == pr.ctypes.data for bf in bufs)
+    with pytest.raises(ValueError):
+        op.hostBuffers(query=nq)
+    for rep in range(2):
+        queries = [(rand_limbs(rng, q, (K, E, 2), N), rand_limbs(rng, q, (2,), N)) for _ in range(nq)]
+        want = [o.pie_run(idx, minus, db, masks, keys[i]) for i, (idx, minus) in enumerate(queries)]
+        for i, (idx, minus) in enumerate(queries):
+            bufs[i][0][...] = idx
+            bufs[i][1][...] = minus
+        pr[...] = 0
+        pieces = [(i, h) for i in range(nq) for h in range(-1, K)]     # h = -1: the minus element
+        pieces = [pieces[j] for j in rng.permutation(len(pieces))]
+        if rep == 1:
+            # a sequence that is abandoned half way (a client hung up): the next piece starts a fresh one
+            for i, h in pieces[:len(pieces) // 2]:
+                op.stageMinus(bufs[i][1], query=i) if h < 0 else op.stageIndexRow(h, bufs[i][0][h], query=i)
+            op.stageReset()
+            with pytest.raises(RuntimeError, match="not staged"):
+                op.runStaged(pr)
+        for n_, (i, h) in enumerate(pieces):
+            if n_ == len(pieces) - 1:
+                with pytest.raises(RuntimeError, match="not staged"):
+                    op.runStaged(pr)
+                # a piece staged twice before the run: the later contents count (here: garbage first, then the query's)
+                garbage = np.zeros_like(bufs[i][1]) if h < 0 else np.zeros_like(bufs[i][0][h])
+                op.stageMinus(garbage, query=i) if h < 0 else op.stageIndexRow(h, garbage, query=i)
+            op.stageMinus(bufs[i][1], query=i) if h < 0 else op.stageIndexRow(h, bufs[i][0][h], query=i)
+        op.runStaged(pr)
+        op.waitHost()
+        for i in range(nq):
+            assert (pr[:, i] == want[i]).all(), "query %d of the staged batch (round %d)" % (i, rep)
+        # the same batch again by the plain entry points (inputs are still in HBM)
+        op.run()
+        got = op.getResultList()
+        for i in range(nq):
+            assert (got[i] == want[i]).all()
+    # the one-call form over pageable arrays
+    queries = [(rand_limbs(rng, q, (K, E, 2), N), rand_limbs(rng, q, (2,), N)) for _ in range(nq)]
+    res = op.runHost(np.stack([x[0] for x in queries]), np.stack([x[1] for x in queries]))
+    for i, (idx, minus) in enumerate(queries):
+        assert (res[:, i] == o.pie_run(idx, minus, db, masks, keys[i])).all()
+    # back to one query per run(): the context's own key again (none loaded here -> a call-order error, then fine)
+    op.setQueryBatch(1)
+    if K > 1:
+        with pytest.raises(RuntimeError, match="key"):
+            op.runHost(queries[0][0], queries[0][1])
+    cc.load_relin_key(keys[0])
+    assert (op.runHost(queries[0][0], queries[0][1]) == o.pie_run(queries[0][0], queries[0][1], db, masks, keys[0])).all()
+    cc.close()
+
+
 @pytest.mark.parametrize("N,L", [(8192, 3), (16384, 4), (32768, 6)])
 def test_extreme_residues_through_run(ob, pie, N, L):
     """residues 0 and q - 1 in every array that enters run() (index matrix, minus element, database, masks, key): the boundary
@@ -907,12 +983,15 @@ def test_extreme_residues_through_run(ob, pie, N, L):
 
 
 # ---- the caller of the hot path as its own process, talking the reference's framing ---------------------------------------
-@pytest.mark.parametrize("shape", ["small", "C3"])
-def test_two_process_psi_over_the_wire(ob, pie, tmp_path, shape):
+@pytest.mark.parametrize("shape,nclients", [("small", 1), ("C3", 1), ("small", 3), ("C3", 3)])
+def test_two_process_psi_over_the_wire(ob, pie, tmp_path, shape, nclients):
     """host/BatchedFHEPSIServer.hpp (C++, reference phase order PSIServer.hpp:66-87) in a child process behind a socket;
     this process plays the client with the product's harness.  The computed intersection equals the true one.  At the
     headline shape (C3: 29 query messages of 1 MiB, 14 result messages) the server's OnlineComputation -- the reference's
-    timer, BatchedFHEPSIServer.cpp:98-106 -- is also bounded: the query's upload runs underneath the receive loop."""
+    timer, BatchedFHEPSIServer.cpp:98-106 -- is also bounded: the query's upload runs underneath the receive loop.
+    nclients = 3: three clients on three channels, each with its own key pair, set and query; the server evaluates their
+    queries as ONE batch (bench.py's default timed region, reached from the reference's call site) and every client
+    recovers exactly its own intersection."""
     import os
     import socket
     import struct
@@ -929,27 +1008,35 @@ def test_two_process_psi_over_the_wire(ob, pie, tmp_path, shape):
         N, L, t = 8192, 3, T32
         k, e, K, E, b = 3, 40, 2, 8, 7
         nS, nC, ninter = 2000, 64, 33
-        items = distinct_items(rng, t, nS + nC)
+        items = distinct_items(rng, t, nS + nclients * nC)
     else:
         N, L, t = 16384, 4, T32
         k, e, K, E, b = 2, 4949, 2, 14, 14
         nS, nC, ninter = 1 << 20, 1 << 10, 513
-        items = np.unique(rng.integers(1, t, nS + nC + 8192, dtype=np.uint64))
+        items = np.unique(rng.integers(1, t, nS + nclients * nC + 8192, dtype=np.uint64))
         rng.shuffle(items)
     server = items[:nS].copy()
-    clientset = np.concatenate([server[:ninter], items[nS:nS + nC - ninter]])
-    rng.shuffle(clientset)
+    clientsets, inters = [], []
+    for c in range(nclients):   # client c shares items [c * 101, c * 101 + ninter) of the server set
+        inter = server[c * 101:c * 101 + ninter]
+        cs = np.concatenate([inter, items[nS + c * nC:nS + c * nC + nC - ninter]])
+        rng.shuffle(cs)
+        clientsets.append(cs)
+        inters.append(inter)
     setfile = tmp_path / "server_set.bin"
     server.astype(np.uint64).tofile(setfile)
-    a, bsock = socket.socketpair()
-    proc = subprocess.Popen([exe, str(bsock.fileno()), str(setfile), str(k), str(e), str(K), str(E), str(b)],
-                            pass_fds=(bsock.fileno(),), stdout=subprocess.PIPE)
-    bsock.close()
+    pairs = [socket.socketpair() for _ in range(nclients)]
+    socks = [p_[0] for p_ in pairs]
+    fds = [p_[1].fileno() for p_ in pairs]
+    proc = subprocess.Popen([exe, ",".join(str(f) for f in fds), str(setfile), str(k), str(e), str(K), str(E), str(b)],
+                            pass_fds=tuple(fds), stdout=subprocess.PIPE)
+    for p_ in pairs:
+        p_[1].close()
 
-    def send(payload):
+    def send(a, payload):
         a.sendall(struct.pack("i", len(payload)) + payload)
 
-    def recv():
+    def recv(a):
         hdr = b""
         while len(hdr) < 4:
             hdr += a.recv(4 - len(hdr))
@@ -962,36 +1049,44 @@ def test_two_process_psi_over_the_wire(ob, pie, tmp_path, shape):
     def ct_msg(ct):
         return struct.pack("IIIIQ", 0x48454950, 1, L, N, 0) + np.ascontiguousarray(ct, dtype=np.uint64).tobytes()
 
-    cc = pie.PieContext(N, L, t)
-    cl = BatchedFHEPSIClient(cc, k, e, K, E, b)
-    evk = cl.runSetUpPhase()
+    ccs = [pie.PieContext(N, L, t) for _ in range(nclients)]
+    cls = [BatchedFHEPSIClient(ccs[c], k, e, K, E, b) for c in range(nclients)]
     moduli = np.zeros(15, dtype=np.uint64)
-    moduli[:2 * L + 1] = cc.moduli[:2 * L + 1]
-    send(struct.pack("IIQ", N, L, t) + moduli.tobytes())          # context
-    send(b"")                                                      # public key (unused by the operator)
-    send(np.ascontiguousarray(evk, dtype=np.uint64).tobytes())     # EvalMult key
-    assert recv() == b""                                           # server: setup phase over
-    minus_ct, idx_ct = cl.runOfflinePhase(clientset)
-    assert recv() == b""                                           # server: offline phase over
-    send(ct_msg(minus_ct))
-    for h in range(K):
-        for j in range(E):
-            send(ct_msg(idx_ct[h, j]))
-    res = []
-    for _ in range(b):
-        m = recv()
-        assert struct.unpack("IIIIQ", m[:24]) == (0x48454950, 1, L, N, 0)
-        res.append(np.frombuffer(m[24:], dtype=np.uint64).reshape(2, L, N))
+    moduli[:2 * L + 1] = ccs[0].moduli[:2 * L + 1]
+    for c, a in enumerate(socks):
+        evk = cls[c].runSetUpPhase(keySeed=11 + 10 * c, evalKeySeed=12 + 10 * c)     # every client its own key pair
+        send(a, struct.pack("IIQ", N, L, t) + moduli.tobytes())          # context
+        send(a, b"")                                                      # public key (unused by the operator)
+        send(a, np.ascontiguousarray(evk, dtype=np.uint64).tobytes())     # EvalMult key
+    for a in socks:
+        assert recv(a) == b""                                             # server: setup phase over
+    queries = [cls[c].runOfflinePhase(clientsets[c], encSeedBase=100 + 1000 * c) for c in range(nclients)]
+    for a in socks:
+        assert recv(a) == b""                                             # server: offline phase over
+    for c, a in enumerate(socks):
+        minus_ct, idx_ct = queries[c]
+        send(a, ct_msg(minus_ct))
+        for h in range(K):
+            for j in range(E):
+                send(a, ct_msg(idx_ct[h, j]))
+    for c, a in enumerate(socks):
+        res = []
+        for _ in range(b):
+            m = recv(a)
+            assert struct.unpack("IIIIQ", m[:24]) == (0x48454950, 1, L, N, 0)
+            res.append(np.frombuffer(m[24:], dtype=np.uint64).reshape(2, L, N))
+        found = cls[c].extractIntersection(np.stack(res))
+        assert sorted(int(v) for v in found) == sorted(int(v) for v in inters[c]), "client %d" % c
     out, _ = proc.communicate(timeout=120)
     assert proc.returncode == 0
     assert b"OnlineComputation," in out and b"OfflineComputation," in out
     online_us = int([ln for ln in out.decode().splitlines() if ln.startswith("OnlineComputation,")][0].split(",")[1])
-    print("two-process PSI, %s shape: server OnlineComputation %d us" % (shape, online_us))
+    print("two-process PSI, %s shape, %d client(s): server OnlineComputation %d us" % (shape, nclients, online_us))
     if shape == "C3":
-        # run() 0.3 ms + 14 MiB of results over PCIe 0.3 ms; the 29 MiB upload overlaps the receive loop (generous bound: a
-        # first query also pays for lazily created queues)
-        assert online_us < 2500
-    found = cl.extractIntersection(np.stack(res))
-    assert sorted(int(v) for v in found) == sorted(int(v) for v in server[:ninter])
-    a.close()
-    cc.close()
+        # one client: run() 0.25 ms + 14 MiB of results over PCIe 0.27 ms; the 29 MiB upload overlaps the receive loop.
+        # three clients: one batched run() 0.64 ms + 42 MiB of results
+        assert online_us < (1200 if nclients == 1 else 2500)
+    for a in socks:
+        a.close()
+    for c_ in ccs:
+        c_.close()

@@ -56,6 +56,17 @@ int main()
             threw = true;
         }
         if (!threw) bad |= 16;
+        // a header that announces more ciphertexts than the message carries is refused before anything is sized by it
+        threw = false;
+        try {
+            const LimbHeader lie = {0x48454950u, 0x7fffffffu, L, N, 0};
+            std::vector<uint8_t> m24(sizeof(lie));
+            std::memcpy(m24.data(), &lie, sizeof(lie));
+            unpackCiphertexts(m24, L, N, got);
+        } catch (const std::invalid_argument &) {
+            threw = true;
+        }
+        if (!threw) bad |= 128;
         // residues must be canonical: one word at its modulus is rejected, all words below it are accepted
         {
             const uint64_t q[2] = {1000003, 1000033};
