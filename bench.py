@@ -712,10 +712,13 @@ def main():
                 args.collective = "all_gather"
             if rank == 0:
                 sys.stderr.write("collective timing (5 rounds, s): %s -> %s\n" % (times, args.collective))
-        # one double-buffered gather per query slot (slots without bin layers still take part in the collective)
+        # one double-buffered gather per query slot (slots without bin layers still take part in the collective); every slot has
+        # a communicator of its own per direction (shard.slot_groups: collectives of one group run in issue order on one stream,
+        # so slots that shared the default group would serialise against each other)
         q_words1 = (K * E * 2 + 2) * L * N   # one query: index matrix, then minus element
+        groups = shard.slot_groups(len(slots))
         rgs = [shard.ResultGather(s_[1], b_total, b_local, ct_words * batch, device, s_[2], kind=args.collective, batch=batch,
-                                  query_words=q_words1) for s_ in slots]
+                                  query_words=q_words1, group=groups[i_][1]) for i_, s_ in enumerate(slots)]
         rg = rgs[0]
     # Per-query input distribution (N > 1): the query ((K E + 1) ciphertexts) is resident in rank 0's HBM and reaches every rank
     # through the slot's QueryBroadcast inside every step -- the second collective of the sharded server, after
@@ -755,13 +758,6 @@ def main():
             qdist_kind = min(times, key=times.get)
             if rank == 0:
                 sys.stderr.write("query distribution timing (s per %.1f MiB query): %s -> %s\n" % (q_words * 8 / 2**20, times, qdist_kind))
-            for rg_ in rgs:
-                qb = shard.QueryBroadcast(q_words, device, src=0, kind=qdist_kind)
-                if flat_h is not None:
-                    qb.set_query_host(flat_h)
-                else:
-                    qb.set_query_device(flat_q)
-                rg_.query, rg_.query_split = qb, q_split
             qdist_times = times
     nstep = [0]
 
@@ -790,24 +786,40 @@ def main():
 
     # Warm-up: at least --warmup steps and at least WARM_SECONDS of them (a 20-step block is 6 ms of GPU time; clocks, caches and
     # the lazily created queues of every slot need longer than that), then REPEATS timed blocks of exactly --steps steps.
-    t_w = time.perf_counter()
-    done_w = 0
-    while True:
-        for _ in range(max(args.warmup, in_flight)):
-            step()
-        done_w += max(args.warmup, in_flight)
-        finish()
-        if agree(time.perf_counter() - t_w, dist.ReduceOp.MIN if dist else None) >= args.warm_seconds:
-            break
-    blocks = []
-    for _ in range(max(1, args.repeats)):
-        finish()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        finish()
-        blocks.append(agree(time.perf_counter() - t0, dist.ReduceOp.MAX if dist else None) / args.steps * 1e3)
+    def run_blocks():
+        t_w = time.perf_counter()
+        while True:
+            for _ in range(max(args.warmup, in_flight)):
+                step()
+            finish()
+            if agree(time.perf_counter() - t_w, dist.ReduceOp.MIN if dist else None) >= args.warm_seconds:
+                break
+        out_ = []
+        for _ in range(max(1, args.repeats)):
+            finish()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            finish()
+            out_.append(agree(time.perf_counter() - t0, dist.ReduceOp.MAX if dist else None) / args.steps * 1e3)
+        return out_
+
+    # The timed region: the queries are resident in HBM when a step starts -- on every rank for N > 1, as on the one GPU of N = 1
+    # (the reference's timer starts after the query has been received, BatchedFHEPSIServer.cpp:94-99; a sharded server distributes
+    # it underneath that receive loop).  N > 1 then times the same steps once more WITH the per-query distribution from rank 0
+    # inside every step (`with_query_distribution` in the line).
+    blocks = run_blocks()
     ms_per_step = median(blocks)
+    dist_blocks = None
+    if rgs and qdist_kind:
+        for i_, rg_ in enumerate(rgs):
+            qb = shard.QueryBroadcast(q_words, device, src=0, kind=qdist_kind, group=groups[i_][0])
+            if flat_h is not None:
+                qb.set_query_host(flat_h)
+            else:
+                qb.set_query_device(flat_q)
+            rg_.query, rg_.query_split = qb, q_split
+        dist_blocks = run_blocks()
 
     # per-kernel times of the same run(), HIP events on the launch stream (separate, untimed passes).  These passes are
     # serial (one stream): with the default two queues a kernel shares the chip with the other queue's kernels and its
@@ -873,9 +885,10 @@ def main():
                                       b_total, b_local, batch, "y" if batch == 1 else "ies", batch * b_total * K * E, batch * b_total * (K - 1),
                                       batch * b_total),
                        "result_ciphertexts_per_step": batch * b_total, "queries_per_step": batch, "parallelism": "bins%d" % world,
-                       "collective": ("%s: %s of the query from rank 0 (%s), %s of results"
-                                      % ("gloo (rehearsal)" if args.rehearse_on_one_gpu else "rccl", qdist_kind or "no distribution",
-                                         args.query_source, args.collective)) if use_dist else "none",
+                       "collective": ("%s: %s of results to rank 0 inside every step, one communicator per query slot and direction; queries "
+                                      "resident on every rank (timed again with %s of the queries from rank 0 (%s): with_query_distribution)"
+                                      % ("gloo (rehearsal)" if args.rehearse_on_one_gpu else "rccl", args.collective,
+                                         qdist_kind or "no distribution", args.query_source)) if use_dist else "none",
                        "query_distribution_s": qdist_times,
                        "queries_in_flight": in_flight},
             "mac_per_s": batch * b_total * K * E / (ms_per_step * 1e-3), "mul_per_s": batch * b_total * (K - 1) / (ms_per_step * 1e-3),
@@ -891,6 +904,14 @@ def main():
                              "note": "bytes of the reference's unfused schedule / measured time / 8 TB/s; not measured HBM traffic"},
             "roofline": roofline, "kernels": kernels,
         }
+        if dist_blocks:
+            dms = median(dist_blocks)
+            line["with_query_distribution"] = {
+                "ms_per_step": dms, "value": batch * b_total / (dms * 1e-3), "ms_per_step_min": min(dist_blocks), "ms_per_step_max": max(dist_blocks),
+                "kind": qdist_kind, "source": args.query_source,
+                "what": "the same steps with every step's %d quer%s (%.1f MiB) travelling from rank 0 to every rank inside the step "
+                        "(shard.QueryBroadcast on the slot's own communicator); `value` above has them resident on every rank"
+                        % (batch, "y" if batch == 1 else "ies", q_words * 8 / 2**20)}
         if world == 1 and op is not None and (in_flight > 1 or batch > 1) and not args.bins_per_rank and not args.timed_only:
             # the same steps with one query at a time (one slot, one query per run(), the library's default of two queues)
             cc.set_run_streams(args.streams)

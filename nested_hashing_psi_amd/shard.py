@@ -87,6 +87,17 @@ def shared_seeds(device=None, src=0, group=None):
     return tuple(int(v) for v in t.cpu())
 
 
+def slot_groups(n_slots):
+    """One process group per direction of every query slot: [(query distribution, result gather)] * n_slots.
+
+    ProcessGroupNCCL runs all collectives of one group on one internal stream in issue order.  With every slot's QueryBroadcast
+    and ResultGather on the default group, the gather of slot s -- which waits for run(s) -- would sit in front of the
+    distribution of slot s + 1's query, so run(s + 1) could not start before run(s) had finished and the slots would not overlap
+    at all.  Each (slot, direction) therefore gets a communicator of its own.  Every rank must call this at the same point
+    (dist.new_group is collective)."""
+    return [(dist.new_group(), dist.new_group()) for _ in range(n_slots)]
+
+
 class QueryBroadcast:
     """Per-query input distribution of the sharded server: one flat array [K E 2 L N + 2 L N] (index matrix, then the minus
     element) travels from rank `src` to every rank, double-buffered like the gather.

@@ -164,3 +164,93 @@ def test_bin_slices_partition():
                 cover += list(range(lo, hi))
                 assert hi - lo <= shard.max_bins(b, world)
             assert cover == list(range(b))
+
+
+def _worker_slot_groups(rank, world, port, b, nslots, q):
+    """bench.py's N > 1 wiring on CPU: every query slot owns a communicator per direction (shard.slot_groups); rank 0 alone knows
+    the queries.  The slots' collectives are then issued in an order that one shared communicator could not serve --
+    every slot's distribution first, the gathers in REVERSE slot order, and the distribution of slot s's NEXT query before slot
+    s's gather has been waited for -- and every gathered result must still equal the unsharded evaluation."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nested_hashing_psi_amd import shard
+        from oracle import binding as ob
+        N, L, t, K, E = 1024, 2, 65537, 2, 3
+        o = ob.Oracle(N, L, t)
+        rng = np.random.default_rng(11)
+
+        def rl(r_, shape):
+            out = np.zeros(shape + (L, N), dtype=np.uint64)
+            for i in range(L):
+                out[..., i, :] = r_.integers(0, int(o.q[i]), shape + (N,), dtype=np.uint64)
+            return out
+
+        db, masks, evk = rl(rng, (K, b, E)), rl(rng, (b,)), rl(rng, (L, 2))
+        lo, hi = shard.bin_slice(b, rank, world)
+        groups = shard.slot_groups(nslots)
+        flat_groups = [g for pair in groups for g in pair]
+        distinct = len({id(g) for g in flat_groups}) == 2 * nslots and all(g is not dist.group.WORLD for g in flat_groups)
+        split = K * E * 2 * L * N
+        qbs = [shard.QueryBroadcast(split + 2 * L * N, "cpu", src=0, kind="broadcast", group=groups[s][0]) for s in range(nslots)]
+        uses_own = all(qbs[s].group is groups[s][0] for s in range(nslots))
+        qrng = np.random.default_rng(2000 + rank)
+        ok = distinct and uses_own
+        bmax = shard.max_bins(b, world)
+        for rnd in range(2):
+            wants, works, outs = [None] * nslots, [None] * nslots, [None] * nslots
+            for s in range(nslots):                       # all distributions of the round first
+                if rank == 0:
+                    idx, minus = rl(qrng, (K, E, 2)), rl(qrng, (2,))
+                    qbs[s].set_query_host(torch.from_numpy(np.concatenate([idx.reshape(-1), minus.reshape(-1)]).view(np.int64)))
+                    wants[s] = o.pie_run(idx, minus, db, masks, evk).reshape(b, 2 * L * N).view(np.int64)
+                qbs[s].step(rnd & 1)
+            for s in reversed(range(nslots)):             # gathers in reverse slot order, asynchronously, on the slot's gather group
+                flat = qbs[s].ready(rnd & 1).numpy().view(np.uint64)
+                idx_r, minus_r = flat[:split].reshape(K, E, 2, L, N), flat[split:split + 2 * L * N].reshape(2, L, N)
+                local = np.zeros((0, 2, L, N), dtype=np.uint64)
+                if hi > lo:
+                    local = o.pie_run(idx_r, minus_r, np.ascontiguousarray(db[:, lo:hi]), np.ascontiguousarray(masks[lo:hi]), evk)
+                local_t = torch.from_numpy(local.reshape(hi - lo, 2 * L * N).view(np.int64))
+                outs[s], works[s] = shard.gather_bins_to(local_t, b, world, dst=0, group=groups[s][1], async_op=True)
+            for s in range(nslots):
+                if works[s] is not None:
+                    works[s].wait()
+                if rank == 0:
+                    rows = [outs[s][r * bmax: r * bmax + (shard.bin_slice(b, r, world)[1] - shard.bin_slice(b, r, world)[0])] for r in range(world)]
+                    ok = ok and bool((torch.cat(rows).numpy() == wants[s]).all())
+        q.put((rank, ok, None))
+    except Exception as e:  # report instead of hanging the parent on q.get
+        import traceback
+        q.put((rank, False, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,b,nslots", [(2, 5, 3), (3, 4, 2)])
+def test_query_slots_own_their_communicators(world, b, nslots):
+    """the slots' collectives may not share one communicator (ProcessGroupNCCL runs a group's collectives in
+    issue order on one stream, so slot s + 1's distribution would wait for slot s's run).  shard.slot_groups gives every slot one
+    group per direction; bench.py passes them to every QueryBroadcast / ResultGather it builds."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_slot_groups, args=(r, world, port, b, nslots, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    # bench.py's wiring: every ResultGather and QueryBroadcast of the timed loop is given a slot group
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tree = ast.parse(open(os.path.join(root, "bench.py")).read())
+    calls = [n for n in ast.walk(tree) if isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute) and n.func.attr in ("ResultGather", "QueryBroadcast")]
+    timed = [c for c in calls if any(k.arg == "group" for k in c.keywords)]
+    probes = [c for c in calls if not any(k.arg == "group" for k in c.keywords)]
+    assert len(timed) >= 2 and {c.func.attr for c in timed} == {"ResultGather", "QueryBroadcast"}
+    # the only constructions without a group are the one-off probes that pick the collective kind before the warm-up
+    assert all(any(isinstance(t, ast.Name) and t.id == "probe" for p_ in ast.walk(tree) if isinstance(p_, ast.Assign) and p_.value is c
+                   for t in p_.targets) for c in probes)
