@@ -229,6 +229,36 @@ int piehip_results_device(piehip_handle h, void **d_out);
 /* enqueue a device-to-device copy of the results into caller-owned HBM (e.g. the RCCL gather buffer) */
 int piehip_copy_results_device(piehip_handle h, void *d_dst);
 
+/* ---- sharded server: one process per GPU, RCCL over xGMI ---------------------------------------------
+ * The outer loop of run() over bin layers (BatchedFHEHIPPIE.cpp:91) has independent iterations: rank r of G evaluates the
+ * bin layers [b r / G, b (r + 1) / G) of the same table (piehip_build_db_bins / piehip_load_db_table_bins with the same seeds)
+ * and holds the EvalMult key(s).  Two exchanges per query, both queued on the handle's stream:
+ *   piehip_rccl_broadcast_query  in: the query reaches the server on ONE rank -- the process that holds the client's socket
+ *                                (BatchedFHEPSIServer.cpp:94-95,114-141).  That rank stages it (piehip_stage_*); then EVERY rank
+ *                                calls this, and every rank's input buffers hold the query (all queries of a batch).
+ *   piehip_gather_results        out: the only exchange of the evaluation itself.  After piehip_run on every rank, each rank's
+ *                                result rows travel to `root` (the rank that answers the client: sendResult, .cpp:143-152) --
+ *                                exact sizes, one transfer per rank, each over its own xGMI link.  d_out on the root:
+ *                                [b_total][nq][2][L][N] in bin order, caller-owned HBM; ignored elsewhere.
+ * RCCL is bound at run time (the copy already in the process, else /opt/rocm's): a one-GPU deployment never loads it.
+ *   piehip_rccl_unique_id   ncclGetUniqueId: 128 bytes made on one rank and handed to the others by the caller's own means
+ *   piehip_rccl_init        ncclCommInitRank on the handle's device (collective over the nranks processes); the handle owns it
+ *   piehip_rccl_attach      or: a communicator (ncclComm_t) the caller made with the process's RCCL; not destroyed here
+ *   piehip_rccl_bin_slice   the bin layers of rank `rank` (what the rank's database must be built for)
+ *   piehip_rccl_broadcast   any device buffer from root to all (set-up traffic: key, seeds) */
+#define PIEHIP_RCCL_ID_BYTES 128
+int piehip_rccl_unique_id(void *id /*[PIEHIP_RCCL_ID_BYTES]*/);
+int piehip_rccl_init(piehip_handle h, const void *id, int nranks, int rank);
+int piehip_rccl_attach(piehip_handle h, void *nccl_comm, int nranks, int rank);
+int piehip_rccl_destroy(piehip_handle h);
+int piehip_rccl_bin_slice(uint32_t b_total, int nranks, int rank, uint32_t *bin_lo, uint32_t *bin_hi);
+int piehip_rccl_broadcast(piehip_handle h, int root, void *d_buf, size_t bytes);
+int piehip_rccl_broadcast_query(piehip_handle h, int root);
+int piehip_gather_results(piehip_handle h, uint32_t b_total, int root, void *d_out);
+/* the same, with the gathered list brought down to host memory on the root: *results (root only; NULL elsewhere) is a page-locked
+ * array [b_total][nq][2][L][N] owned by the handle, complete after piehip_sync -- what sendResult (.cpp:143-152) reads */
+int piehip_gather_results_host(piehip_handle h, uint32_t b_total, int root, uint64_t **results);
+
 /* ---- the OpenFHE primitives under run(), exposed one by one for kernel-level parity tests ------
  * (host buffers in, host buffers out; synchronous) */
 /* DCRTPoly::SetFormat on nlimbs limbs [nlimbs][N]; limb i uses modulus mod_base + (i % mod_count) */

@@ -68,6 +68,15 @@ SYMBOLS = {
     "piehip_get_results": (C.c_int, [C.c_void_p, u64p]),
     "piehip_results_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "piehip_copy_results_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "piehip_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "piehip_rccl_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "piehip_rccl_attach": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "piehip_rccl_destroy": (C.c_int, [C.c_void_p]),
+    "piehip_rccl_bin_slice": (C.c_int, [C.c_uint32, C.c_int, C.c_int, u32p, u32p]),
+    "piehip_rccl_broadcast": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "piehip_rccl_broadcast_query": (C.c_int, [C.c_void_p, C.c_int]),
+    "piehip_gather_results": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
+    "piehip_gather_results_host": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(u64p)]),
     "piehip_ntt": (C.c_int, [C.c_void_p, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     "piehip_eval_add": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "piehip_eval_mult_plain": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),

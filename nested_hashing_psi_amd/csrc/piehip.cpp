@@ -378,6 +378,7 @@ int piehip_destroy(piehip_handle h)
     if (h->db_borrowers) return fail(PIEHIP_ESTATE, "destroy: other handles still use this handle's database (destroy them first)");
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)piehip_rccl_destroy(h);
     for (hipEvent_t e : h->pool) (void)hipEventDestroy(e);
     detach_database(h);
     dev_free(&h->d_evk);

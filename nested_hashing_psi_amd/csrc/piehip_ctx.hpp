@@ -151,6 +151,12 @@ struct piehip_ctx {
     u64 *d_prod = nullptr;  // [b][2][L][N]  (K > 2 only)
     u64 *d_out = nullptr;   // [b][2][L][N]
     piehip::MulWs ws;
+    // sharded server (piehip_rccl.cpp): this handle's rank in an RCCL communicator (ncclComm_t; owned if piehip_rccl_init made it)
+    void *comm = nullptr;
+    bool comm_owned = false;
+    int comm_ranks = 0, comm_rank = 0;
+    u64 *d_gather = nullptr, *pin_gather = nullptr;   // the root's gathered result list [b_total][nq][2][L][N]: HBM, page-locked host
+    size_t gather_words = 0;
     // rotation-based PIE (FHEHIPPIE): rotation keys by index, EVALUATION index maps, packed sub-tables
     std::map<int32_t, u64 *> rotkeys;   // [L][2][L][N] each
     std::map<int32_t, u32 *> rotmaps;   // [N] each

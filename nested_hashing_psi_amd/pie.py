@@ -46,6 +46,19 @@ def tabulation_hash(hash_seed, nfun, hf, x):
     return out
 
 
+def rccl_unique_id():
+    """ncclGetUniqueId through the library's RCCL binding: 128 bytes for piehip_rccl_init on every rank"""
+    buf = (C.c_ubyte * 128)()
+    _check(lib().piehip_rccl_unique_id(buf))
+    return bytes(buf)
+
+
+def rccl_bin_slice(b_total, nranks, rank):
+    lo, hi = C.c_uint32(), C.c_uint32()
+    _check(lib().piehip_rccl_bin_slice(int(b_total), int(nranks), int(rank), C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
 def default_moduli(N, L):
     q = np.zeros(L, dtype=np.uint64)
     p = np.zeros(L + 1, dtype=np.uint64)
@@ -165,6 +178,15 @@ class PieContext:
             _check(lib().piehip_load_relin_key(self._h, ap))
         else:
             _check(lib().piehip_load_relin_key_q(self._h, int(query), ap))
+
+    # -- sharded server over RCCL behind the C ABI (piehip_rccl.cpp): what a C++ server calls; shard.py is the torch.distributed way
+    def rccl_init(self, unique_id, nranks, rank):
+        """join the communicator made from `unique_id` (rccl_unique_id() of one rank, handed to the others by the caller)"""
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        _check(lib().piehip_rccl_init(self._h, buf, int(nranks), int(rank)))
+
+    def rccl_destroy(self):
+        _check(lib().piehip_rccl_destroy(self._h))
 
     def rotation_galois(self, index):
         """Galois element 5^index mod 2N of the row rotation by `index` (EvalAtIndex convention: > 0 rotates left)"""
@@ -434,6 +456,21 @@ class BatchedFHEHIPPIE:
         _check(lib().piehip_get_results(self.cc._h, out.ctypes.data_as(u64p)))
         # a query batch: the library's rows are [bin layer][query]; hand back [query][bin layer] (a view)
         return out if nq == 1 else out.transpose(1, 0, 2, 3, 4)
+
+    def broadcastQuery(self, root=0):
+        """the query staged on rank `root` (stageMinus / stageIndexRow) reaches every rank's input buffers (piehip_rccl_broadcast_query)"""
+        _check(lib().piehip_rccl_broadcast_query(self.cc._h, int(root)))
+
+    def gatherResultsHost(self, b_total, root=0):
+        """after run() on every rank: the b_total result ciphertexts in bin order on rank `root`, as a page-locked numpy view owned by
+        the library (None on the other ranks); complete after sync()  (piehip_gather_results_host)"""
+        p = u64p()
+        _check(lib().piehip_gather_results_host(self.cc._h, int(b_total), int(root), C.byref(p)))
+        if not p:
+            return None
+        nq = self.nq
+        shape = (b_total, 2, self.cc.L, self.cc.N) if nq == 1 else (b_total, nq, 2, self.cc.L, self.cc.N)
+        return np.ctypeslib.as_array(p, shape=shape)
 
     def copyResultsToDevice(self, ptr):
         _check(lib().piehip_copy_results_device(self.cc._h, ptr))

@@ -139,6 +139,46 @@ def test_cpp_server_harness_compiles(built, tmp_path):
     assert subprocess.call([exe]) == 2  # usage error: no arguments
 
 
+def test_cpp_sharded_server_compiles(built, tmp_path):
+    """host/ShardedBatchedFHEPSIServer.hpp -- one process per GPU, the query distribution and the final gather over RCCL behind the
+    C ABI (piehip_rccl_*, piehip_gather_results*) -- builds warning-free against the library alone: no RCCL headers, no torch.
+    It runs with one rank in tests/test_sharding_gpu.py::test_cpp_server_over_rccl_one_rank."""
+    import subprocess
+    libdir = os.path.join(ROOT, "nested_hashing_psi_amd")
+    exe = str(tmp_path / "sharded_server_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "sharded_server_main.cpp"),
+                           "-L" + libdir, "-lpiehip", "-Wl,-rpath," + libdir])
+    assert subprocess.call([exe]) == 2  # usage error: no arguments
+    # the library does not LINK against RCCL (bound at run time: a one-GPU deployment never loads it)
+    needed = subprocess.check_output(["readelf", "-d", os.path.join(libdir, "libpiehip.so")]).decode()
+    assert "rccl" not in needed
+
+
+def test_rccl_entry_points_check_their_arguments(built):
+    """call-order / argument errors of the sharded entry points need neither a GPU nor RCCL"""
+    import ctypes as C
+    from nested_hashing_psi_amd import _lib
+    L = _lib.lib()
+    lo, hi = C.c_uint32(), C.c_uint32()
+    assert L.piehip_rccl_bin_slice(14, 8, 3, C.byref(lo), C.byref(hi)) == 0 and (lo.value, hi.value) == (5, 7)
+    cover = []
+    for r in range(8):
+        assert L.piehip_rccl_bin_slice(14, 8, r, C.byref(lo), C.byref(hi)) == 0
+        cover += list(range(lo.value, hi.value))
+    assert cover == list(range(14))
+    from nested_hashing_psi_amd import shard
+    assert all(shard.bin_slice(14, r, 8) == tuple(_slice(L, 14, 8, r)) for r in range(8))   # the same partition as the Python harness
+    assert L.piehip_rccl_bin_slice(14, 8, 8, C.byref(lo), C.byref(hi)) == -1
+    assert L.piehip_gather_results(None, 14, 0, None) == -1 and L.piehip_rccl_broadcast_query(None, 0) == -1
+
+
+def _slice(L, b, G, r):
+    import ctypes as C
+    lo, hi = C.c_uint32(), C.c_uint32()
+    assert L.piehip_rccl_bin_slice(b, G, r, C.byref(lo), C.byref(hi)) == 0
+    return lo.value, hi.value
+
+
 def test_client_parameter_selection_follows_the_reference():
     """BatchedFHEPSIClient.cpp:22-57: plaintext modulus by bit size, depth by inner table size, ring 16384"""
     import pytest

@@ -363,3 +363,136 @@ def test_c4_eight_bin_slices_in_one_process(ob, pie_mod):
         cc.close()
     assert sorted(sizes) == [1, 1, 2, 2, 2, 2, 2, 2]
     _c3_check(ob, o, sk, queries[0], rows, _c3_oracle_results(ob, o, oslots, mask_slots, evk, queries[0]))
+
+
+# ---- RCCL behind the C ABI (piehip_rccl.cpp): what a C++ server calls -------------------------------------------------------
+def test_native_rccl_gather_one_rank(ob, pie_mod):
+    """piehip_rccl_unique_id / _init / _broadcast_query / piehip_gather_results_host with one rank (RCCL refuses two ranks on the one
+    device of the test box): the staged query reaches the input buffers, run() evaluates it, the gathered list in page-locked host
+    memory equals the oracle's run(); also for a batch of three queries, and the call-order errors."""
+    pie = pie_mod
+    N, L, t, K, E, b = 4096, 2, 65537, 2, 4, 5
+    o = ob.Oracle(N, L, t)
+    rng = np.random.default_rng(99)
+
+    def rl(shape):
+        out = np.zeros(shape + (L, N), dtype=np.uint64)
+        for i in range(L):
+            out[..., i, :] = rng.integers(0, int(o.q[i]), shape + (N,), dtype=np.uint64)
+        return out
+
+    db, masks, evk = rl((K, b, E)), rl((b,)), rl((L, 2))
+    cc = pie.PieContext(N, L, t)
+    cc.load_relin_key(evk)
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    with pytest.raises(RuntimeError, match="communicator"):
+        op.gatherResultsHost(b)
+    assert pie.rccl_bin_slice(b, 1, 0) == (0, b)
+    cc.rccl_init(pie.rccl_unique_id(), 1, 0)
+    with pytest.raises(RuntimeError, match="already"):
+        cc.rccl_init(pie.rccl_unique_id(), 1, 0)
+    with pytest.raises(RuntimeError, match="no staged query"):
+        op.broadcastQuery(0)
+    for nq in (1, 3):
+        op.setQueryBatch(nq)
+        queries = [(rl((K, E, 2)), rl((2,))) for _ in range(nq)]
+        bufs = [op.hostBuffers(query=i) for i in range(nq)]
+        for i, (idx, minus) in enumerate(queries):
+            bufs[i][0][...] = idx
+            bufs[i][1][...] = minus
+            op.stageMinus(bufs[i][1], query=i)
+            if i == nq - 1:
+                with pytest.raises(RuntimeError, match="not staged"):
+                    op.broadcastQuery(0)
+            for h in range(K):
+                op.stageIndexRow(h, bufs[i][0][h], query=i)
+        op.broadcastQuery(0)
+        op.run(sync=False)
+        with pytest.raises(ValueError, match="slice"):
+            op.gatherResultsHost(b + 1)
+        got = op.gatherResultsHost(b, root=0)
+        op.sync()
+        for i, (idx, minus) in enumerate(queries):
+            want = o.pie_run(idx, minus, db, masks, evk)
+            assert ((got if nq == 1 else got[:, i]) == want).all(), "query %d of %d" % (i, nq)
+    cc.rccl_destroy()
+    cc.close()
+
+
+@pytest.mark.parametrize("shape", ["small", "C3"])
+def test_cpp_server_over_rccl_one_rank(pie_mod, tmp_path, shape):
+    """host/ShardedBatchedFHEPSIServer.hpp as its own process -- C++ over the C ABI only, no torch: context, key and seeds through its
+    set-up, the database built for the rank's bin layers, the query staged under the receive loop, piehip_rccl_broadcast_query +
+    piehip_run + piehip_gather_results_host inside the reference's timer.  One rank (one GPU here); this process is the client."""
+    import os
+    import socket
+    import struct
+    import subprocess
+    from nested_hashing_psi_amd.client import BatchedFHEPSIClient
+    pie = pie_mod
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "nested_hashing_psi_amd")
+    exe = str(tmp_path / "sharded_server_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(root, "tests", "sharded_server_main.cpp"),
+                           "-L" + libdir, "-lpiehip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    rng = np.random.default_rng(4242)
+    if shape == "small":
+        N, L, t, k, e, K, E, b, nS, nC, ninter = 8192, 3, T32, 3, 40, 2, 8, 7, 2000, 64, 33
+    else:
+        N, L, t, k, e, K, E, b, nS, nC, ninter = C3["N"], C3["L"], T32, C3["k"], C3["e"], C3["K"], C3["E"], C3["b"], C3["nS"], C3["nC"], 513
+    items = np.unique(rng.integers(1, t, nS + nC + 8192, dtype=np.uint64))
+    rng.shuffle(items)
+    server = items[:nS].copy()
+    clientset = np.concatenate([server[:ninter], items[nS:nS + nC - ninter]])
+    rng.shuffle(clientset)
+    setfile = tmp_path / "server_set.bin"
+    server.astype(np.uint64).tofile(setfile)
+    a, bsock = socket.socketpair()
+    proc = subprocess.Popen([exe, "0", "1", "0", str(bsock.fileno()), "-", str(setfile), str(k), str(e), str(K), str(E), str(b)],
+                            pass_fds=(bsock.fileno(),), stdout=subprocess.PIPE)
+    bsock.close()
+
+    def send(payload):
+        a.sendall(struct.pack("i", len(payload)) + payload)
+
+    def recv():
+        hdr = b""
+        while len(hdr) < 4:
+            hdr += a.recv(4 - len(hdr))
+        n, = struct.unpack("i", hdr)
+        buf = bytearray()
+        while len(buf) < n:
+            buf += a.recv(min(1 << 20, n - len(buf)))
+        return bytes(buf)
+
+    def ct_msg(ct):
+        return struct.pack("IIIIQ", 0x48454950, 1, L, N, 0) + np.ascontiguousarray(ct, dtype=np.uint64).tobytes()
+
+    cc = pie.PieContext(N, L, t)
+    cl = BatchedFHEPSIClient(cc, k, e, K, E, b)
+    evk = cl.runSetUpPhase()
+    moduli = np.zeros(15, dtype=np.uint64)
+    moduli[:2 * L + 1] = cc.moduli[:2 * L + 1]
+    send(struct.pack("IIQ", N, L, t) + moduli.tobytes())
+    send(b"")
+    send(np.ascontiguousarray(evk, dtype=np.uint64).tobytes())
+    assert recv() == b""
+    minus_ct, idx_ct = cl.runOfflinePhase(clientset)
+    assert recv() == b""
+    send(ct_msg(minus_ct))
+    for h in range(K):
+        for j in range(E):
+            send(ct_msg(idx_ct[h, j]))
+    res = []
+    for _ in range(b):
+        m = recv()
+        assert struct.unpack("IIIIQ", m[:24]) == (0x48454950, 1, L, N, 0)
+        res.append(np.frombuffer(m[24:], dtype=np.uint64).reshape(2, L, N))
+    out, _ = proc.communicate(timeout=180)
+    assert proc.returncode == 0
+    online_us = int([ln for ln in out.decode().splitlines() if ln.startswith("OnlineComputation,")][0].split(",")[1])
+    print("C++ server over RCCL (one rank), %s shape: OnlineComputation %d us" % (shape, online_us))
+    found = cl.extractIntersection(np.stack(res))
+    assert sorted(int(v) for v in found) == sorted(int(v) for v in server[:ninter])
+    a.close()
+    cc.close()
