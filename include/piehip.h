@@ -164,6 +164,9 @@ int piehip_host_buffers_q(piehip_handle h, uint32_t q, uint64_t **idx, uint64_t 
  * a C3 query cross PCIe while the remaining messages are still arriving, i.e. before the reference's timer starts (.cpp:98-99).
  *   piehip_stage_minus(_q)      the minus element [2][L][N] (of query q of the batch; pieces of different queries in any order)
  *   piehip_stage_index_row(_q)  row `row` (one inner hash function) of the index matrix, [E][2][L][N]
+ *   piehip_stage_index_ct_q     one ciphertext (row, j) of the index matrix, [2][L][N] -- one message of the reference's receive loop
+ *                               (.cpp:124-141): when the timer starts (.cpp:98) at most the last message's megabyte is still on
+ *                               its way, not the last row's fourteen
  *   piehip_run_staged           setMinusCompareElement + setIndex + run + getResultList on the staged pieces: stage A of row h waits
  *                               for row h of every query of the batch only; results ([b][nq][2][L][N], may be NULL) are complete
  *                               after piehip_run_host_wait.
@@ -174,6 +177,7 @@ int piehip_stage_minus(piehip_handle h, const uint64_t *minus);
 int piehip_stage_index_row(piehip_handle h, uint32_t row, const uint64_t *row_data);
 int piehip_stage_minus_q(piehip_handle h, uint32_t q, const uint64_t *minus);
 int piehip_stage_index_row_q(piehip_handle h, uint32_t q, uint32_t row, const uint64_t *row_data);
+int piehip_stage_index_ct_q(piehip_handle h, uint32_t q, uint32_t row, uint32_t j, const uint64_t *ct);
 int piehip_stage_reset(piehip_handle h);
 int piehip_run_staged(piehip_handle h, uint64_t *results);
 /* Stream order.  run() works on the handle's own queues (piehip_set_run_streams); it waits for the handle's stream

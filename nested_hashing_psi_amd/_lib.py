@@ -52,6 +52,7 @@ SYMBOLS = {
     "piehip_run_staged": (C.c_int, [C.c_void_p, u64p]),
     "piehip_stage_minus_q": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
     "piehip_stage_index_row_q": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u64p]),
+    "piehip_stage_index_ct_q": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, u64p]),
     "piehip_stage_reset": (C.c_int, [C.c_void_p]),
     "piehip_host_buffers_q": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(u64p), C.POINTER(u64p), C.POINTER(u64p)]),
     "piehip_load_relin_key_q": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),

@@ -167,6 +167,20 @@ __device__ __forceinline__ u64 csub_neg(u64 x, u64 negm)
     return ((u64)hi << 32) | lo;
 }
 
+// Global addresses are "uniform base + 32-bit lane offset in BYTES" (the global_load / global_store form with a scalar base
+// register pair and one vector offset register).  Written with element offsets the scaling happens after the zero-extension, the
+// compiler can no longer prove that the offset fits 32 bits, and every access pattern keeps a 64-bit per-lane offset pair alive
+// across the item loop (eight registers instead of four, and 64-bit vector adds per access).
+__device__ __forceinline__ const u64 *at_bytes(const u64 *ubase, u32 boff)
+{
+    return reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(ubase) + boff);
+}
+__device__ __forceinline__ u64 *at_bytes(u64 *ubase, u32 boff) { return reinterpret_cast<u64 *>(reinterpret_cast<char *>(ubase) + boff); }
+__device__ __forceinline__ const u64x2 *at_bytes(const u64x2 *ubase, u32 boff)
+{
+    return reinterpret_cast<const u64x2 *>(reinterpret_cast<const char *>(ubase) + boff);
+}
+
 // the CPT coefficients a thread holds of row r (pass 1): x[CPT r .. CPT r + CPT)
 template <u32 CPT>
 __device__ __forceinline__ void row_get(u64 *x, int r, const u64 *p)
@@ -188,6 +202,30 @@ __device__ __forceinline__ void row_put(const u64 *x, int r, u64 *p)
     } else {
         *p = x[r];
     }
+}
+// the slice's way out to HBM
+template <u32 CPT>
+__device__ __forceinline__ void row_put_global(const u64 *x, int r, u64 *p)
+{
+#ifdef NTT16_NT_STORES
+    if (CPT == 2) {
+        u64x2 v;
+        v.x = x[2 * r], v.y = x[2 * r + 1];
+        __builtin_nontemporal_store(v, reinterpret_cast<u64x2 *>(p));
+    } else {
+        __builtin_nontemporal_store(x[r], p);
+    }
+#else
+    row_put<CPT>(x, r, p);
+#endif
+}
+__device__ __forceinline__ void pair_put_global(u64x2 v, u64 *p)
+{
+#ifdef NTT16_NT_STORES
+    __builtin_nontemporal_store(v, reinterpret_cast<u64x2 *>(p));
+#else
+    *reinterpret_cast<u64x2 *>(p) = v;
+#endif
 }
 
 // DS operations of one wave execute in issue order: a hand-off inside the wave only needs the compiler kept from
@@ -317,8 +355,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
     u64 *const p2 = lds + phi(1024 * w + l);
     u64 *const p3 = lds + 1088 * w + 68 * la + lc;
     u64 *const p4 = lds + phi(1024 * w + 16 * l);
-    const u32 voff = 2 * tau;    // lane offset (in words) of the lane-ordered pairs 2 (T j + tau)
-    const u32 coff = CPT * tau;  // ... and of the row accesses 1024 r + CPT tau (pass 1)
+
     u64 x[16];
     // item -> (limb, slice of the limb); forward launches may enumerate [nb][4][skip_M] without the Q limbs of slots 0, 1
     auto limb_of = [&](u32 it) -> u32 {
@@ -331,29 +368,43 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
         return lb;
     };
     for (u32 item = blockIdx.x; item < a.nitems; item += gridDim.x) {
+        // The lane offsets are made opaque once per item: as loop invariants the compiler widens them to 64-bit pairs, adds the
+        // table bases it can hoist, keeps all of that alive across the loop -- and, at this kernel's register budget, spills it.
+        // Only the thread index itself is carried from item to item; the four offsets are a handful of instructions per slice.
+        u32 tau_ = tau;
+        asm volatile("" : "+v"(tau_));
+        const u32 voffb = 16 * tau_;       // lane offset (in bytes) of the lane-ordered pairs 2 (T j + tau)
+        const u32 coffb = 8 * CPT * tau_;  // ... and of the row accesses 1024 r + CPT tau (pass 1)
+        const u32 lab = 4 * (tau_ & 60), lb = 16 * (tau_ & 63);  // ... and into the kernel-ordered twiddle tables of passes 3 (16 la) and 4 (16 l)
         const bool lift = LIFT && !INV && item >= a.lift_first;
         const u32 item_l = lift ? item - a.lift_first : item;
         const u32 blk = item_l & ((1u << a.s0) - 1);
         const u32 limb = lift ? item_l >> a.s0 : limb_of(item);
-        u64 *const g = (lift ? a.data2 : a.data) + (((size_t)limb << a.s0) + blk) * NS;  // uniform
+        // (uniform; laundered through a scalar register pair so that the slice's addresses stay "scalar base + lane offset": left to
+        // itself the compiler hoists a.data + lane offset out of the item loop as a 64-bit vector base, which the inverse kernel
+        // -- at its 128-register budget -- spilled to scratch, and a scratch reload is a vector-memory operation: the
+        // s_waitcnt vmcnt(0) in front of its use drained the previous slice's stores and this slice's twiddle loads before the
+        // first data load was even issued)
+        u64 *g = (lift ? a.data2 : a.data) + (((size_t)limb << a.s0) + blk) * NS;
+        asm("" : "+s"(g));
         const u32 mod = __builtin_amdgcn_readfirstlane(a.mod_base + limb % a.mod_count);
-        const DcS dcs = (DcS)uniform_addr(a.dc);
+        const DcS dcs = (DcS)(u64)a.dc;
         const u64 q = dcs->mod[mod].q;
         const u64 q2 = 2 * q, q4 = 4 * q;
         ModC mc;
         mc.nql = (u32)(0 - q), mc.nqh = (u32)((0 - q) >> 32), mc.nq4 = 0 - q4, mc.q4 = q4;
-        const TwS tw = (TwS)uniform_addr(a.twp + ((size_t)mod * 2 + (INV ? 1 : 0)) * a.N);
+        const TwS tw = (TwS)(u64)(a.twp + ((size_t)mod * 2 + (INV ? 1 : 0)) * a.N);
         const u64x2 *__restrict__ twk = a.twk + (((size_t)mod * 2 + (INV ? 1 : 0)) << a.s0) * TWK_PER_SLICE + (size_t)blk * TWK_PER_SLICE;
         const u64x2 *__restrict__ tw3 = twk + (size_t)w * 15 * 16;                 // [slot 0..14][16 a]
         const u64x2 *__restrict__ tw4 = twk + G::W * 15 * 16 + (size_t)w * 12 * 64;   // [slot 0..11][64 l]
         // per-lane twiddles of passes 3 and 4, loaded one stage ahead of their use (named by stage: 7, 8, 9, 10, 11, 12)
         u64x2 t7[1], t8[2], t9[4], t10[8], t11[4], t12[8];
 #define NTT16_LOAD3(dst, sc)                                                       \
-    _Pragma("unroll") for (int j_ = 0; j_ < (1 << (sc)); j_++) dst[j_] = tw3[16 * ((1 << (sc)) - 1 + j_) + la]
+    _Pragma("unroll") for (int j_ = 0; j_ < (1 << (sc)); j_++) dst[j_] = *at_bytes(tw3 + 16 * ((1 << (sc)) - 1 + j_), lab)
 #define NTT16_LOAD3H(dst, sc, from)                                                \
-    _Pragma("unroll") for (int j_ = (from); j_ < (from) + 4; j_++) dst[j_] = tw3[16 * ((1 << (sc)) - 1 + j_) + la]
+    _Pragma("unroll") for (int j_ = (from); j_ < (from) + 4; j_++) dst[j_] = *at_bytes(tw3 + 16 * ((1 << (sc)) - 1 + j_), lab)
 #define NTT16_LOAD4(dst, first, n)                                                 \
-    _Pragma("unroll") for (int j_ = 0; j_ < (n); j_++) dst[j_] = tw4[64 * ((first) + j_) + l]
+    _Pragma("unroll") for (int j_ = 0; j_ < (n); j_++) dst[j_] = *at_bytes(tw4 + 64 * ((first) + j_), lb)
 
         if (!INV) {
             NTT16_STAMP(0);
@@ -390,8 +441,8 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                     u64 y[16];  // the other half of the limb
 #pragma unroll
                     for (int r = 0; r < (int)R; r++) {
-                        row_get<CPT>(x, r, src + 1024 * r + coff);
-                        row_get<CPT>(y, r, src + NS + 1024 * r + coff);
+                        row_get<CPT>(x, r, at_bytes(src + 1024 * r, coffb));
+                        row_get<CPT>(y, r, at_bytes(src + NS + 1024 * r, coffb));
                     }
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
@@ -401,13 +452,13 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < (int)R; r++) row_get<CPT>(x, r, src + 1024 * r + coff);
+                    for (int r = 0; r < (int)R; r++) row_get<CPT>(x, r, at_bytes(src + 1024 * r, coffb));
 #pragma unroll
                     for (int k = 0; k < 16; k++) x[k] = lift1(x[k]);
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < (int)R; r++) row_get<CPT>(x, r, g + 1024 * r + coff);
+                for (int r = 0; r < (int)R; r++) row_get<CPT>(x, r, at_bytes(g + 1024 * r, coffb));
             }
             NTT16_PRIO_F(1);
 #pragma unroll
@@ -502,7 +553,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                 bfly2<false, false>(x[4 * g4], x[4 * g4 + 2], t, x[4 * g4 + 1], x[4 * g4 + 3], t, mc);
                 if (g4 == 1) {
                     NTT16_FENCE();
-                    _Pragma("unroll") for (int j_ = 4; j_ < 8; j_++) t12[j_] = tw4[64 * (4 + j_) + l];
+                    _Pragma("unroll") for (int j_ = 4; j_ < 8; j_++) t12[j_] = *at_bytes(tw4 + 64 * (4 + j_), lb);
                     NTT16_FENCE();
                 }
             }
@@ -523,22 +574,37 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                 u64x2 v;
                 v.x = r0;
                 v.y = r1;
-                *reinterpret_cast<u64x2 *>(g + 2 * T * j + voff) = v;
+                pair_put_global(v, at_bytes(g + 2 * T * j, voffb));
             }
             NTT16_STAMP(8);
         } else {
             // ---- input: 16 contiguous coefficients per thread -------------------------------------------------------------
             NTT16_PRIO_I(0);
-            NTT16_LOAD4(t12, 4, 8);
+            NTT16_LOAD4(t12, 4, 4);   // (the other four behind the data loads: the register budget is x 32 + twiddles)
             if (a.flags & F_STD_IN) {
-                // standard order: coalesced rows through LDS
+                // Standard order in.  A wave's pass-4' elements are the 1024 contiguous coefficients of its own block: it loads
+                // exactly those (coalesced: pair 64 j + l of the block per lane and instruction), drops them into its own region of
+                // the image and picks up its 16 contiguous coefficients -- a hand-off inside the wave.  (Until r04 the slice
+                // came in as the rows of pass 1 -- columns across all waves -- which took a second workgroup barrier.)
                 u64 yv[16];
+                const u64 *gw = g + 1024 * w;
 #pragma unroll
-                for (int r = 0; r < (int)R; r++) row_get<CPT>(yv, r, g + 1024 * r + coff);
-                __syncthreads();  // previous slice's readers of the image are done
+                for (int j = 0; j < 8; j++) {
+                    const u64x2 v = *reinterpret_cast<const u64x2 *>(at_bytes(gw + 128 * j, lb));
+                    yv[2 * j] = v.x, yv[2 * j + 1] = v.y;
+                }
+                __syncthreads();  // previous slice's readers of the image (pass 1' of every wave) are done
+                {
+                    // element 1024 w + 128 j + 2 l at phi(.): phi is additive over multiples of 32, 128 j -> 136 j
+                    u64 *const pw = lds + phi(1024 * w + 2 * l);
 #pragma unroll
-                for (int r = 0; r < (int)R; r++) row_put<CPT>(yv, r, p1 + 1088 * r);
-                __syncthreads();
+                    for (int j = 0; j < 8; j++) {
+                        u64x2 v;
+                        v.x = yv[2 * j], v.y = yv[2 * j + 1];
+                        *reinterpret_cast<u64x2 *>(pw + 136 * j) = v;
+                    }
+                }
+                wave_sync();
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const u64x2 v = *reinterpret_cast<const u64x2 *>(p4 + 2 * j);
@@ -549,30 +615,37 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                 if (a.copy_out && (limb / (2 * a.copy_L)) % a.copy_K == 0) {
                     const u32 bin = limb / (2 * a.copy_L * a.copy_K), cc = (limb / a.copy_L) & 1, i = limb % a.copy_L;
                     u64 *co = a.copy_out + (((((size_t)bin * 4 + cc) * a.copy_M + i) << a.s0) + blk) * NS;
+                    asm("" : "+s"(co));
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
                         u64x2 v;
                         v.x = x[2 * j];
                         v.y = x[2 * j + 1];
-                        *reinterpret_cast<u64x2 *>(co + 2 * T * j + voff) = v;
+                        *reinterpret_cast<u64x2 *>(at_bytes(co + 2 * T * j, voffb)) = v;
                     }
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const u64x2 v = *reinterpret_cast<const u64x2 *>(g + 2 * T * j + voff);
+                    const u64x2 v = *reinterpret_cast<const u64x2 *>(at_bytes(g + 2 * T * j, voffb));
                     x[2 * j] = v.x;
                     x[2 * j + 1] = v.y;
                 }
             }
             NTT16_FENCE();
+            _Pragma("unroll") for (int j_ = 4; j_ < 8; j_++) t12[j_] = *at_bytes(tw4 + 64 * (4 + j_), lb);
+            NTT16_FENCE();
             NTT16_PRIO_I(1);
             // ---- pass 4': stages 12, 11 ----------------------------------------------------------------------------------------
-            NTT16_LOAD4(t11, 0, 4);
-            NTT16_FENCE();
 #pragma unroll
-            for (int k = 0; k < 16; k += 4)  // stage 12
+            for (int k = 0; k < 16; k += 4) {  // stage 12
                 bfly2<true, false>(x[k], x[k + 1], make_tw(t12[k >> 1]), x[k + 2], x[k + 3], make_tw(t12[(k >> 1) + 1]), mc);
+                if (k == 4) {   // the first half of this stage's twiddles is dead: the next stage's take their registers
+                    NTT16_FENCE();
+                    NTT16_LOAD4(t11, 0, 4);
+                    NTT16_FENCE();
+                }
+            }
             NTT16_LOAD3(t10, 3);
             NTT16_FENCE();
 #pragma unroll
@@ -666,7 +739,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                 }
             }
 #pragma unroll
-            for (int r = 0; r < (int)R; r++) row_put<CPT>(x, r, g + 1024 * r + coff);
+            for (int r = 0; r < (int)R; r++) row_put_global<CPT>(x, r, at_bytes(g + 1024 * r, coffb));
         }
     }
 }

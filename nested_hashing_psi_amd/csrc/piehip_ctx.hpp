@@ -72,6 +72,7 @@ struct MulWs {
 struct QueryStage {
     u64 *pin_idx = nullptr, *pin_minus = nullptr;  // page-locked staging [K][E][2][L][N], [2][L][N]
     std::vector<bool> rows;                        // pieces on their way since the staging sequence began
+    std::vector<bool> cts;                         // ... ciphertext by ciphertext (piehip_stage_index_ct_q), [K][E]
     bool minus = false;
 };
 

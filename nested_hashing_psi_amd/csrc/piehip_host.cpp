@@ -88,6 +88,7 @@ static int stage_begin(piehip_ctx *h, u32 q)
     for (u32 i = 0; i < h->nq; i++) {
         h->qstage[i].minus = false;
         h->qstage[i].rows.assign(h->K, false);
+        h->qstage[i].cts.clear();
     }
     return PIEHIP_OK;
 }
@@ -165,6 +166,26 @@ int piehip_stage_index_row_q(piehip_handle h, uint32_t q, uint32_t row, const ui
     return upload_staged(h);
 }
 
+int piehip_stage_index_ct_q(piehip_handle h, uint32_t q, uint32_t row, uint32_t j, const uint64_t *ct)
+{
+    if (!h) return fail(PIEHIP_EINVAL, "null handle");
+    if (!ct) return fail(PIEHIP_EINVAL, "null input");
+    int rc = stage_begin(h, q);
+    if (rc) return rc;
+    if (row >= h->K || j >= h->E) return fail(PIEHIP_EINVAL, "stage_index_ct: position outside the [K][E] index matrix");
+    u64 *di = nullptr, *dm = nullptr;
+    if ((rc = query_input_buffers(h, q, &di, &dm))) return rc;
+    const size_t words = 2 * h->LN();
+    HIPCHK(hipMemcpyAsync(di + ((size_t)row * h->E + j) * words, ct, words * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    QueryStage &s = h->qstage[q];
+    if (s.cts.size() != (size_t)h->K * h->E) s.cts.assign((size_t)h->K * h->E, false);
+    s.cts[(size_t)row * h->E + j] = true;
+    bool all = true;
+    for (u32 i = 0; i < h->E && all; i++) all = s.cts[(size_t)row * h->E + i];
+    if (all) s.rows[row] = true;
+    return upload_staged(h);
+}
+
 int piehip_stage_minus(piehip_handle h, const uint64_t *minus) { return piehip_stage_minus_q(h, 0, minus); }
 int piehip_stage_index_row(piehip_handle h, uint32_t row, const uint64_t *row_data) { return piehip_stage_index_row_q(h, 0, row, row_data); }
 
@@ -175,6 +196,7 @@ int piehip_stage_reset(piehip_handle h)
     for (QueryStage &s : h->qstage) {
         s.minus = false;
         s.rows.assign(s.rows.size(), false);
+        s.cts.clear();
     }
     return PIEHIP_OK;
 }

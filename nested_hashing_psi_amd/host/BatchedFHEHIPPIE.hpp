@@ -225,15 +225,13 @@ public:
         std::fill(rowCount.begin(), rowCount.end(), 0u);
         rowsStaged = arrived = 0;
     }
-    // ciphertext (h, j) has been written to indexStaging(h, j); the row's upload starts when its E ciphertexts have arrived
+    // ciphertext (h, j) has been written to indexStaging(h, j): its upload starts now
     void stageIndexCiphertext(uint32_t h, uint32_t j)
     {
         if (h >= K || j >= E) throw std::invalid_argument("index matrix position out of range");
+        PieContext::check(piehip_stage_index_ct_q(cc.handle(), 0, h, j, indexStaging(h, j)));  // leaves at once
         arrived++;
-        if (++rowCount[h] == E) {
-            PieContext::check(piehip_stage_index_row(cc.handle(), h, indexStaging(h, 0)));
-            rowsStaged++;
-        }
+        if (++rowCount[h] == E) rowsStaged++;
     }
     void stageMinus()
     {
@@ -333,11 +331,9 @@ public:
     {
         checkQuery(q);
         if (h >= K || j >= E) throw std::invalid_argument("index matrix position out of range");
+        PieContext::check(piehip_stage_index_ct_q(cc.handle(), q, h, j, indexStaging(q, h, j)));
         st[q].arrived++;
-        if (++st[q].rowCount[h] == E) {
-            PieContext::check(piehip_stage_index_row_q(cc.handle(), q, h, indexStaging(q, h, 0)));
-            st[q].rowsStaged++;
-        }
+        if (++st[q].rowCount[h] == E) st[q].rowsStaged++;
     }
     void stageMinus(uint32_t q)
     {

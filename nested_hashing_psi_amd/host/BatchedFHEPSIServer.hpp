@@ -149,8 +149,8 @@ public:
                        b = ht.maxItemsPerPosition, nq = (uint32_t)fds.size();
         const size_t ct = 2 * (size_t)L * N;
         // Every message is unpacked (and range-checked) straight into the library's page-locked staging arrays, and a piece's
-        // upload starts as soon as it is complete: the minus element at once, row h of the index matrix when its E messages
-        // have landed -- the 29 MiB of a C3 query cross PCIe underneath the receive loop (the reference deserialises into
+        // upload starts as soon as it has landed: every message's ciphertext at once -- the 29 MiB of a C3 query cross PCIe
+        // underneath the receive loop, and when the timer starts only the last megabyte is still on its way (the reference deserialises into
         // Ciphertext objects in the same place, .cpp:114-141, before its timer starts at .cpp:98).  A failed receive drops the
         // partial staging (piehip_stage_reset) before the exception leaves.
         uint64_t *pinRes = nullptr;
@@ -163,13 +163,12 @@ public:
                 wire::readWithSizeIntoVector(fd, m);  // receiveEncryptedMinusElements, .cpp:114-122
                 wire::unpackCiphertextsInto(m, L, N, pinMinus, 1, qMod.data());
                 PieContext::check(piehip_stage_minus_q(cc->handle(), q, pinMinus));
-                for (uint32_t h = 0; h < K; h++) {  // receiveIndexMatrix, .cpp:124-141: one message per ciphertext
+                for (uint32_t h = 0; h < K; h++)  // receiveIndexMatrix, .cpp:124-141: one message per ciphertext, staged as it lands
                     for (uint32_t j = 0; j < E; j++) {
                         wire::readWithSizeIntoVector(fd, m);
                         wire::unpackCiphertextsInto(m, L, N, pinIdx + ((size_t)h * E + j) * ct, 1, qMod.data());
+                        PieContext::check(piehip_stage_index_ct_q(cc->handle(), q, h, j, pinIdx + ((size_t)h * E + j) * ct));
                     }
-                    PieContext::check(piehip_stage_index_row_q(cc->handle(), q, h, pinIdx + (size_t)h * E * ct));
-                }
             }
         } catch (...) {
             piehip_stage_reset(cc->handle());

@@ -148,13 +148,12 @@ public:
                 wire::readWithSizeIntoVector(fd, m);  // receiveEncryptedMinusElements, .cpp:114-122
                 wire::unpackCiphertextsInto(m, L, N, pinMinus, 1, qMod.data());
                 PieContext::check(piehip_stage_minus(cc->handle(), pinMinus));
-                for (uint32_t h = 0; h < K; h++) {  // receiveIndexMatrix, .cpp:124-141
+                for (uint32_t h = 0; h < K; h++)  // receiveIndexMatrix, .cpp:124-141: every message staged as it lands
                     for (uint32_t j = 0; j < E; j++) {
                         wire::readWithSizeIntoVector(fd, m);
                         wire::unpackCiphertextsInto(m, L, N, pinIdx + ((size_t)h * E + j) * ct, 1, qMod.data());
+                        PieContext::check(piehip_stage_index_ct_q(cc->handle(), 0, h, j, pinIdx + ((size_t)h * E + j) * ct));
                     }
-                    PieContext::check(piehip_stage_index_row(cc->handle(), h, pinIdx + (size_t)h * E * ct));
-                }
             } catch (...) {
                 piehip_stage_reset(cc->handle());
                 throw;

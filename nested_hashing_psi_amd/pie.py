@@ -419,6 +419,12 @@ class BatchedFHEHIPPIE:
             raise ValueError("an index matrix row is E contiguous uint64 ciphertexts")
         _check(lib().piehip_stage_index_row_q(self.cc._h, int(query), int(row), rowCiphertexts.ctypes.data_as(u64p)))
 
+    def stageIndexCiphertext(self, row, j, ciphertext, query=0):
+        """start the upload of ciphertext (row, j) of query `query`'s index matrix, [2][L][N] (piehip_stage_index_ct_q)"""
+        if ciphertext.dtype != np.uint64 or not ciphertext.flags.c_contiguous or ciphertext.shape != (2, self.cc.L, self.cc.N):
+            raise ValueError("an index matrix entry is one contiguous uint64 ciphertext")
+        _check(lib().piehip_stage_index_ct_q(self.cc._h, int(query), int(row), int(j), ciphertext.ctypes.data_as(u64p)))
+
     def stageReset(self):
         """drop a partial staging sequence (piehip_stage_reset)"""
         _check(lib().piehip_stage_reset(self.cc._h))

@@ -215,9 +215,11 @@ int main(int argc, char **argv)
     std::vector<u32> sizes;
     for (int i = 1; i < argc; i++) sizes.push_back((u32)atoi(argv[i]));
     if (sizes.empty()) sizes = {224, 448, 512, 756, 784, 1024, 2048, 4096};
-    for (int inv = 0; inv < 2; inv++)
+    // inv = 2: the run()'s first inverse launch -- standard order in (stage A's accumulators), the lane-ordered copy of the X
+    // operand's limbs written on the side (K = 2 ciphertexts of 2 x 3 limbs per row; rows of 12 limbs)
+    for (int inv = 0; inv < 3; inv++)
         for (u32 nitems : sizes) {
-            u64 *d;
+            u64 *d, *d_copy = nullptr;
             CK(hipMalloc((void **)&d, (size_t)nitems * NS * 8));
             CK(hipMemset(d, 1, (size_t)nitems * NS * 8));
             Args a;
@@ -225,6 +227,13 @@ int main(int argc, char **argv)
             a.data = d, a.twp = (const u64x2 *)d_twp, a.twk = (const u64x2 *)d_twk, a.dc = d_dc, a.N = N, a.s0 = s0, a.nitems = nitems;
             a.mod_base = 0, a.mod_count = nmod;
             a.flags = inv ? F_FOLDED : F_LAZY_OUT;
+            if (inv == 2) {
+                a.flags |= F_STD_IN;
+                a.copy_K = 2, a.copy_L = nmod, a.copy_M = 2 * nmod + 1;
+                const size_t rows = ((nitems >> s0) + 4 * nmod - 1) / (4 * nmod);
+                CK(hipMalloc((void **)&d_copy, rows * 4 * a.copy_M * N * 8));
+                a.copy_out = d_copy;
+            }
             const u32 grid = nitems < LAB_SLOTS ? nitems : LAB_SLOTS;
             a.lift_first = ~0u;
             hipEvent_t e0, e1;
@@ -243,9 +252,10 @@ int main(int argc, char **argv)
             float ms;
             CK(hipEventElapsedTime(&ms, e0, e1));
             const double us = ms * 1e3 / iters;
-            printf("%s nitems=%5u  %8.2f us/launch  %6.2f slices/us  %7.1f GB/s alg (%.3f of 8 TB/s)\n", inv ? "inv" : "fwd", nitems, us,
+            printf("%s nitems=%5u  %8.2f us/launch  %6.2f slices/us  %7.1f GB/s alg (%.3f of 8 TB/s)\n", inv == 2 ? "inv std-in + copy" : inv ? "inv" : "fwd", nitems, us,
                    nitems / us, 16.0 * NS * nitems / (us * 1e-6) / 1e9, 16.0 * NS * nitems / (us * 1e-6) / 8e12);
             CK(hipFree(d));
+            if (d_copy) CK(hipFree(d_copy));
         }
     return 0;
 }
