@@ -322,13 +322,15 @@ inline u32 lane_to_std(u32 p) { return lane_to_std_t(p, T); }
 // slice).  With the priority tied to progress the wave that is behind is served first and all arrive together.  Forward: the
 // barrier sits after pass 1, so pass 2 is the start of the cycle and pass 1 of the NEXT slice its end (lowest priority; its
 // loads are issued at the highest, they are a handful of instructions): 2048 slices 88.2 -> 82.5 us against "pass 1 highest",
-// the run's ragged launches unchanged (profiles/r03/ntt16_lab_wave_priorities.txt).  Inverse: barriers after pass 4' and pass 2'.
+// the run's ragged launches unchanged (profiles/r03/ntt16_lab_wave_priorities.txt).  Inverse (r04): both barriers sit between
+// pass 2' and pass 1' (around the row reads), so pass 1' opens the cycle and pass 2' closes it at the lowest priority
+// (profiles/r04/ntt16_lab_wave_priorities_inverse.txt).
 #define NTT16_PASS_PRIO(p) __builtin_amdgcn_s_setprio(p)
 #ifndef NTT16_PF
 #define NTT16_PF 3, 0, 3, 2, 1   // forward: loads, pass 1, pass 2, pass 3, pass 4
 #endif
 #ifndef NTT16_PI
-#define NTT16_PI 3, 3, 2, 1, 0   // inverse: loads, pass 4', pass 3', pass 2', pass 1'
+#define NTT16_PI 3, 3, 2, 0, 1   // inverse: loads, pass 4', pass 3', pass 2', pass 1'
 #endif
 #define NTT16_PRIO_PICK_(i, a0, a1, a2, a3, a4) ((i) == 0 ? (a0) : (i) == 1 ? (a1) : (i) == 2 ? (a2) : (i) == 3 ? (a3) : (a4))
 #define NTT16_PRIO_PICK(i, ...) NTT16_PRIO_PICK_(i, __VA_ARGS__)
@@ -579,6 +581,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
             NTT16_STAMP(8);
         } else {
             // ---- input: 16 contiguous coefficients per thread -------------------------------------------------------------
+            NTT16_STAMP(0);
             NTT16_PRIO_I(0);
             NTT16_LOAD4(t12, 4, 4);   // (the other four behind the data loads: the register budget is x 32 + twiddles)
             if (a.flags & F_STD_IN) {
@@ -593,7 +596,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                     const u64x2 v = *reinterpret_cast<const u64x2 *>(at_bytes(gw + 128 * j, lb));
                     yv[2 * j] = v.x, yv[2 * j + 1] = v.y;
                 }
-                __syncthreads();  // previous slice's readers of the image (pass 1' of every wave) are done
+                // (the image is free: every wave passed the barrier behind the previous slice's pass-1' reads)
                 {
                     // element 1024 w + 128 j + 2 l at phi(.): phi is additive over multiples of 32, 128 j -> 136 j
                     u64 *const pw = lds + phi(1024 * w + 2 * l);
@@ -653,9 +656,10 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                 const Tw t = make_tw(t11[g4]);
                 bfly2<true, false>(x[4 * g4], x[4 * g4 + 2], t, x[4 * g4 + 1], x[4 * g4 + 3], t, mc);
             }
-            // lane order in: no barrier so far in this slice, and the stores below overwrite the image that the other waves'
-            // pass 1' of the previous slice may still be reading
-            if (!(a.flags & F_STD_IN)) __syncthreads();
+            NTT16_STAMP(1);
+            // (the stores below overwrite the image the other waves read in pass 1' of the previous slice: they are behind the
+            // barrier that follows those reads)
+            NTT16_STAMP(2);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 u64x2 v;
@@ -664,6 +668,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                 *reinterpret_cast<u64x2 *>(p4 + 2 * j) = v;
             }
             wave_sync();
+            NTT16_STAMP(3);
             // ---- pass 3': stages 10..7 -----------------------------------------------------------------------------------------
             NTT16_PRIO_I(2);
 #pragma unroll
@@ -695,6 +700,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
 #pragma unroll
             for (int k = 0; k < 16; k++) p3[4 * k + 2 * (k >> 3)] = x[k];
             wave_sync();
+            NTT16_STAMP(4);
             // ---- pass 2': stages 6..3 ------------------------------------------------------------------------------------------
             NTT16_PRIO_I(3);
 #pragma unroll
@@ -712,11 +718,19 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
             }
 #pragma unroll
             for (int k = 0; k < 16; k++) p2[68 * k] = x[k];
+            NTT16_STAMP(5);
             __syncthreads();
+            NTT16_STAMP(6);
             // ---- pass 1': the top LOGR stages, stored straight to HBM ------------------------------------------------------------------
             NTT16_PRIO_I(4);
 #pragma unroll
             for (int r = 0; r < (int)R; r++) row_get<CPT>(x, r, p1 + 1088 * r);
+            // The image is free from here on.  This is where the workgroup waits for "everybody has read it", not in front of the
+            // next slice's first stores: the waves come out of the barrier above together and read eight rows each, so nobody
+            // waits here -- behind pass 4' of the next slice the older half of the waves stood 9 000 of a slice's 42 000 cycles
+            // waiting for the younger half (equal priorities: the arbiter serves the oldest wave first;
+            // profiles/r04/ntt16_lab_cycle_stamps_inverse.txt).
+            __syncthreads();
 #pragma unroll
             for (int s = (int)LOGR - 1; s >= 0; s--) {
                 const int d = (int)(R >> 1) >> s;
@@ -728,6 +742,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                     for (int c = 0; c < (int)CPT; c++) bfly<true, true>(x[CPT * r + c], x[CPT * (r + d) + c], t, mc);
                 }
             }
+            NTT16_STAMP(7);
             const u64 n_inv = dcs->mod[mod].n_inv, n_inv_sh = dcs->mod[mod].n_inv_sh;
             if (!(a.flags & F_FOLDED)) {
 #pragma unroll
@@ -740,6 +755,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
             }
 #pragma unroll
             for (int r = 0; r < (int)R; r++) row_put_global<CPT>(x, r, at_bytes(g + 1024 * r, coffb));
+            NTT16_STAMP(8);
         }
     }
 }

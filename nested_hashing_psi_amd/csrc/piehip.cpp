@@ -1120,7 +1120,8 @@ namespace piehip {
 u32 run_group_size(u32 b, u32 ng, u32 g)
 {
     if (ng == 2) {
-        const u32 first = (4 * b + 3) / 7;
+        u32 first = (4 * b + 3) / 7;
+        if (const char *lab = getenv("PIEHIP_LAB_SPLIT")) first = std::min<u32>(b - 1, std::max(1, atoi(lab)));   // lab sweep
         return g == 0 ? first : b - first;
     }
     return b / ng + (g < b % ng ? 1 : 0);

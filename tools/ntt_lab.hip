@@ -184,6 +184,7 @@ int main(int argc, char **argv)
 #endif
 
 #ifdef LAB_STAMPS
+    for (int inv = 0; inv < 2; inv++)
     for (u32 grid : {LAB_SLOTS / 2, LAB_SLOTS}) {
         const u32 nitems = 3 * grid;
         u64 *d;
@@ -193,17 +194,21 @@ int main(int argc, char **argv)
         memset(&a, 0, sizeof(a));
         a.data = d, a.twp = (const u64x2 *)d_twp, a.twk = (const u64x2 *)d_twk, a.dc = d_dc, a.N = N, a.s0 = s0, a.nitems = nitems;
         a.mod_base = 0, a.mod_count = nmod;
-        a.flags = F_LAZY_OUT;
+        a.flags = inv ? F_FOLDED : F_LAZY_OUT;
         a.lift_first = ~0u;
-        for (int rep = 0; rep < 400; rep++) hipLaunchKernelGGL((ntt16_kernel_t<LAB_LOGNS, false>), dim3(grid), dim3(T), lds, 0, a);
+        for (int rep = 0; rep < 400; rep++) {
+            if (inv) hipLaunchKernelGGL((ntt16_kernel_t<LAB_LOGNS, true>), dim3(grid), dim3(T), lds, 0, a);
+            else hipLaunchKernelGGL((ntt16_kernel_t<LAB_LOGNS, false>), dim3(grid), dim3(T), lds, 0, a);
+        }
         CK(hipDeviceSynchronize());
         unsigned long long st[16 * 16];
         CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st)));
-        static const char *names[9] = {"load", "pass1", "barA", "ldsW", "barB", "rd+pass2", "pass3", "pass4", "store"};
-        printf("forward, %u blocks (%.1f per CU): cycles per phase of the second slice (s_memtime ticks)\n", grid, grid / 256.0);
+        static const char *names[2][9] = {{"load", "pass1", "barA", "ldsW", "barB", "rd+pass2", "pass3", "pass4", "store"},
+                                          {"-", "ld+pass4'", "barA", "ldsW", "pass3'", "pass2'", "barB", "pass1'", "store"}};
+        printf("%s, %u blocks (%.1f per CU): cycles per phase of the second slice (s_memtime ticks)\n", inv ? "inverse (lane order in)" : "forward", grid, grid / 256.0);
         for (int w = 0; w < (int)LG::W; w++) {
             printf("  wave %d:", w);
-            for (int i = 1; i <= 8; i++) printf(" %s %llu", names[i], st[w * 16 + i] - st[w * 16 + i - 1]);
+            for (int i = 1; i <= 8; i++) printf(" %s %llu", names[inv][i], st[w * 16 + i] - st[w * 16 + i - 1]);
             printf("  | total %llu cycles in %.2f us -> %.2f GHz\n", st[w * 16 + 8] - st[w * 16 + 0], (st[w * 16 + 10] - st[w * 16 + 9]) / 100.0,
                    (double)(st[w * 16 + 8] - st[w * 16 + 0]) / ((st[w * 16 + 10] - st[w * 16 + 9]) * 10.0));
         }
