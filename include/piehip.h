@@ -172,7 +172,10 @@ int piehip_host_buffers_q(piehip_handle h, uint32_t q, uint64_t **idx, uint64_t 
  *                               after piehip_run_host_wait.
  *   piehip_stage_reset          drops a partial staging sequence (a receive failed between two pieces): the next piece begins a
  *                               new one.  Staging a piece again before the run simply replaces it.
- * PIEHIP_ESTATE when a piece is missing.  piehip_run_host_async is exactly: stage_minus, stage_index_row for every row, run_staged. */
+ * PIEHIP_ESTATE when a piece is missing.  piehip_run_host_async is exactly: stage_minus, stage_index_row for every row, run_staged.
+ * Queries of one device go up one after the other, in the order they were staged: the first piece of a staging sequence waits
+ * (on the host) until the pieces other handles staged before it have left host memory -- uploads that share the link finish
+ * together and the slots fall into lock-step (piehip_host.cpp). */
 int piehip_stage_minus(piehip_handle h, const uint64_t *minus);
 int piehip_stage_index_row(piehip_handle h, uint32_t row, const uint64_t *row_data);
 int piehip_stage_minus_q(piehip_handle h, uint32_t q, const uint64_t *minus);

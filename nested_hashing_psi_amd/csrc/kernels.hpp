@@ -156,6 +156,8 @@ void launch_rot_prepare(const DevConsts *dc, u32 N, u32 L, const u64 *x, const u
                         u64 *d01, u64 *d2, u32 nct, hipStream_t st);
 void launch_sum_mul_plain(const DevConsts *dc, u32 N, u32 L, const u64 *x, u32 group, const u64 *pt, size_t pt_stride, u64 *out,
                           size_t out_stride, u32 ngroups, hipStream_t st);
+// writes `value` to a word of page-locked host memory (its device address) behind everything queued on `st` so far
+void launch_host_flag(u64 *flag_dev, u64 value, hipStream_t st);
 // element-wise helpers on nct ciphertexts [nct][2][L][N]
 void launch_ct_add(const DevConsts *dc, u32 N, u32 L, const u64 *x, const u64 *y, u64 *out, u32 nct, hipStream_t st);
 // (pt_div > 1: ciphertext i takes plaintext i / pt_div)

@@ -1327,6 +1327,19 @@ void launch_relin_mac(const DevConsts *dc, u32 N, u32 L, const u64 *d01, size_t 
 #undef RM
 }
 
+// One word for the host: `value` lands in page-locked host memory when everything queued on the stream before it is done
+// (piehip_host.cpp: "the uploads of this query have left host memory" -- an event cannot say that once kernels are queued
+// behind the uploads: hipEventSynchronize on an earlier event waits for the stream's whole backlog).
+__global__ void host_flag_kernel(volatile u64 *flag, u64 value)
+{
+    *flag = value;
+    __threadfence_system();
+}
+void launch_host_flag(u64 *flag_dev, u64 value, hipStream_t st)
+{
+    hipLaunchKernelGGL(host_flag_kernel, dim3(1), dim3(1), 0, st, (volatile u64 *)flag_dev, value);
+}
+
 // ---------------------------------------------------------------------------------------------
 // EvalAdd / EvalMult(ct,pt) as stand-alone element-wise kernels (rows A3, A4)
 // ---------------------------------------------------------------------------------------------

@@ -502,15 +502,28 @@ static void free_workspace(piehip_ctx *h)
     dev_free(&h->d_prod);
     dev_free(&h->d_out);
     ws_free(h->ws);
+    h->ws_cap_rows = h->ws_cap_K = 0;
 }
+// Every array of the workspace is indexed by row first, so one sized for more rows serves fewer as it stands: a smaller batch
+// keeps the larger allocation (a server that alternates between batch sizes would otherwise free and allocate 0.6 GiB per change,
+// and what the allocator hands back after such churn is not what it handed out first: uploads into input buffers allocated later
+// ran at half the link rate in some sequences of bench.py's legs).
 static int alloc_workspace(piehip_ctx *h, u32 K, u32 b)
 {
     const size_t LN = h->LN(), rows = (size_t)b * h->nq;
+    if (h->d_acc && h->d_out && h->ws.eqp && h->ws_cap_K == K && rows <= h->ws_cap_rows && (K <= 2 || h->d_prod)) {
+        h->ws.nb = (u32)rows;
+        return PIEHIP_OK;
+    }
+    free_workspace(h);
     int rc;
     if ((rc = dev_alloc(&h->d_acc, rows * K * 2 * LN))) return rc;
     if ((rc = dev_alloc(&h->d_out, rows * 2 * LN))) return rc;
     if (K > 2 && (rc = dev_alloc(&h->d_prod, rows * 2 * LN))) return rc;
-    return ws_alloc(h, h->ws, (u32)rows);
+    if ((rc = ws_alloc(h, h->ws, (u32)rows))) return rc;
+    h->ws_cap_rows = rows;
+    h->ws_cap_K = K;
+    return PIEHIP_OK;
 }
 
 static int alloc_run_buffers(piehip_ctx *h, u32 K, u32 b, u32 E, bool with_db = true)
@@ -963,7 +976,6 @@ int piehip_set_query_batch(piehip_handle h, uint32_t nq)
     h->evkq_n = h->evkq_loaded = 0;
     h->nq = nq;
     if (!h->K) return PIEHIP_OK;  // the database's arrival sizes the workspace
-    free_workspace(h);
     return alloc_workspace(h, h->K, h->b);
 }
 int piehip_get_query_batch(piehip_handle h, uint32_t *nq)

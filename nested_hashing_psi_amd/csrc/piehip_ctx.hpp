@@ -101,7 +101,8 @@ struct piehip_ctx {
     // all transfers travel on the handle's own queues (no copy stream: see piehip_host.cpp)
     piehip::QueryStage qstage[piehip::STAGE_A_MAX_QUERIES];
     bool stage_open = false;                      // piehip_stage_*: the uploads of the next run()'s queries have begun
-    hipEvent_t ev_up = nullptr;                   // behind this handle's last staged piece (the next upload of the device queues behind it)
+    u64 *pin_up_flag = nullptr;                   // page-locked word: sequence number of the last query of this handle whose uploads have
+    u64 up_seq = 0;                               // left host memory (written by a one-thread kernel behind them); the next number
     u64 *host_results = nullptr;                  // set while piehip_run_staged enqueues: every queue group downloads its slice there
     u64 *pin_res = nullptr;                       // [b][nq][2][L][N]
     size_t pin_idx_words = 0, pin_res_words = 0;
@@ -152,6 +153,8 @@ struct piehip_ctx {
     u64 *d_prod = nullptr;  // [b][2][L][N]  (K > 2 only)
     u64 *d_out = nullptr;   // [b][2][L][N]
     piehip::MulWs ws;
+    size_t ws_cap_rows = 0;   // rows (bin layer x query) the workspace arrays were allocated for; ws.nb = rows in use
+    u32 ws_cap_K = 0;
     // sharded server (piehip_rccl.cpp): this handle's rank in an RCCL communicator (ncclComm_t; owned if piehip_rccl_init made it)
     void *comm = nullptr;
     bool comm_owned = false;

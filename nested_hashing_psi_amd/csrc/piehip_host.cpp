@@ -17,34 +17,60 @@
 // Upload order.  Uploads of different handles that are in flight together share the link, finish together, evaluate together and
 // download together: a stream of queries over several slots falls into lock-step -- every slot uploading, then every slot
 // computing, then every slot downloading, never one direction busy while the other is (same trace).  The queries of a device
-// therefore go up in the order they were staged, one at a time at the full link rate: a staging sequence begins behind the
-// last piece any handle of the device has staged (one event wait per query).  While query i + 1 crosses PCIe, query i
-// evaluates and its results come down.
+// therefore go up one after the other at the full link rate: a staging sequence does not begin before the query another handle
+// of the device handed over last (piehip_run_staged) has left host memory.  While query i + 1 crosses PCIe, query i evaluates
+// and its results come down.  How the host learns "has left host memory":
+//   * not from a stream-side event wait -- a barrier packet again: 0.64 -> 1.4 ms per query over three slots once the
+//     process owns more than four streams;
+//   * not from hipEventSynchronize on an event recorded behind the uploads -- with kernels queued behind that event it returns
+//     when the stream's whole backlog is done (measured: the wait covered the other slot's evaluation and download too);
+//   * from a word in page-locked memory that a one-thread kernel, queued between the uploads and the evaluation, sets to the
+//     query's sequence number.  The staging host thread polls it.
 #include "piehip_ctx.hpp"
 
+#include <chrono>
 #include <mutex>
+#include <thread>
 
 using namespace piehip;
 
 namespace {
+struct LastUpload {
+    const volatile u64 *flag = nullptr;   // the uploading handle's page-locked word
+    u64 seq = 0;                          // ... reads >= seq once that query's uploads are done
+    const piehip_ctx *owner = nullptr;
+};
 std::mutex g_up_mutex;
-std::map<int, hipEvent_t> g_last_up;   // per device: recorded behind the most recently staged piece (the event is its handle's)
+std::map<int, LastUpload> g_last_up;   // per device
 }  // namespace
 
-// the first piece of a staging sequence waits for the uploads staged before it on this device, whichever handle they belong to
+// the first piece of a staging sequence waits (on the host) for the query another handle handed over last on this device
 static int upload_turn(piehip_ctx *h)
 {
-    if (!h->ev_up) HIPCHK(hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming));
-    std::lock_guard<std::mutex> lock(g_up_mutex);
-    const hipEvent_t last = g_last_up[h->device];
-    if (last && last != h->ev_up) HIPCHK(hipStreamWaitEvent(h->stream, last, 0));
+    if (!h->pin_up_flag) {
+        HIPCHK(hipHostMalloc((void **)&h->pin_up_flag, 64, hipHostMallocPortable));
+        *h->pin_up_flag = 0;
+    }
+    std::lock_guard<std::mutex> lock(g_up_mutex);   // (held while waiting: the word's owner cannot free it, nobody jumps the queue)
+    const LastUpload last = g_last_up[h->device];
+    if (last.flag && last.owner != h) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (__atomic_load_n(last.flag, __ATOMIC_ACQUIRE) < last.seq) {
+            std::this_thread::yield();
+            // a stream that never gets there (a failed launch) must not hang the other handles: order is a matter of speed only
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
+        }
+    }
     return PIEHIP_OK;
 }
-static int upload_staged(piehip_ctx *h)
+// behind the staged pieces of a query, in front of its evaluation
+static int upload_handed_over(piehip_ctx *h)
 {
-    HIPCHK(hipEventRecord(h->ev_up, h->stream));
+    void *dev = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&dev, h->pin_up_flag, 0));
+    launch_host_flag((u64 *)dev, ++h->up_seq, h->stream);
     std::lock_guard<std::mutex> lock(g_up_mutex);
-    g_last_up[h->device] = h->ev_up;
+    g_last_up[h->device] = LastUpload{h->pin_up_flag, h->up_seq, h};
     return PIEHIP_OK;
 }
 
@@ -52,14 +78,14 @@ namespace piehip {
 
 void free_host_path(piehip_ctx *h)
 {
-    if (h->ev_up) {
+    if (h->pin_up_flag) {
         {
             std::lock_guard<std::mutex> lock(g_up_mutex);
             auto it = g_last_up.find(h->device);
-            if (it != g_last_up.end() && it->second == h->ev_up) g_last_up.erase(it);
+            if (it != g_last_up.end() && it->second.owner == h) g_last_up.erase(it);
         }
-        (void)hipEventDestroy(h->ev_up);
-        h->ev_up = nullptr;
+        (void)hipHostFree(h->pin_up_flag);
+        h->pin_up_flag = nullptr;
     }
     for (QueryStage &s : h->qstage) {
         if (s.pin_idx) (void)hipHostFree(s.pin_idx);
@@ -148,7 +174,7 @@ int piehip_stage_minus_q(piehip_handle h, uint32_t q, const uint64_t *minus)
     if ((rc = query_input_buffers(h, q, &di, &dm))) return rc;
     HIPCHK(hipMemcpyAsync(dm, minus, 2 * h->LN() * sizeof(u64), hipMemcpyHostToDevice, h->stream));
     h->qstage[q].minus = true;
-    return upload_staged(h);
+    return PIEHIP_OK;
 }
 
 int piehip_stage_index_row_q(piehip_handle h, uint32_t q, uint32_t row, const uint64_t *row_data)
@@ -163,7 +189,7 @@ int piehip_stage_index_row_q(piehip_handle h, uint32_t q, uint32_t row, const ui
     const size_t words = (size_t)h->E * 2 * h->LN();
     HIPCHK(hipMemcpyAsync(di + (size_t)row * words, row_data, words * sizeof(u64), hipMemcpyHostToDevice, h->stream));
     h->qstage[q].rows[row] = true;
-    return upload_staged(h);
+    return PIEHIP_OK;
 }
 
 int piehip_stage_index_ct_q(piehip_handle h, uint32_t q, uint32_t row, uint32_t j, const uint64_t *ct)
@@ -183,7 +209,7 @@ int piehip_stage_index_ct_q(piehip_handle h, uint32_t q, uint32_t row, uint32_t 
     bool all = true;
     for (u32 i = 0; i < h->E && all; i++) all = s.cts[(size_t)row * h->E + i];
     if (all) s.rows[row] = true;
-    return upload_staged(h);
+    return PIEHIP_OK;
 }
 
 int piehip_stage_minus(piehip_handle h, const uint64_t *minus) { return piehip_stage_minus_q(h, 0, minus); }
@@ -221,8 +247,10 @@ int piehip_run_staged(piehip_handle h, uint64_t *results)
     // the uploads are on the handle's stream and the run's queues start behind it (the inputs changed); every queue group's slice
     // of the result list leaves on that group's queue as soon as the group is done
     mark_dirty(h);
+    int rc = upload_handed_over(h);
+    if (rc) return rc;
     h->host_results = results;
-    const int rc = piehip_run_into(h, h->d_out);
+    rc = piehip_run_into(h, h->d_out);
     h->host_results = nullptr;
     return rc;
 }

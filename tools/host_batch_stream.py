@@ -10,6 +10,7 @@ from nested_hashing_psi_amd import pie
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 nslots = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+one_call = len(sys.argv) > 4 and sys.argv[4] == "async"   # piehip_run_host_async instead of the piecewise calls (batch 1)
 N, L, t, K, E, b, B = 16384, 4, 4296540161, 2, 14, 14, 9898
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(1)
@@ -44,7 +45,9 @@ def stream(nb):
         o, qb = ops[i % nslots], bufs[i % nslots]
         if i >= nslots:
             o.waitHost()
-        if i < nb:
+        if i < nb and one_call:
+            o.runHostAsync(qb[0][0], qb[0][1], qb[0][2])
+        elif i < nb:
             for q in range(batch):
                 o.stageMinus(qb[q][1], query=q)
             for h in range(K):
