@@ -863,6 +863,8 @@ def main():
             ach = ntt_bytes / (ntt_ms * 1e-3) / 1e9
             roofline = {"kernel": "ntt (forward+inverse, LDS-resident limb)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config),
+                        "traffic_source": "HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/latest_pmc.json: "
+                                          "FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run",
                         "avg_launch_us": 1e3 * ntt_ms / ntt_launch, "alg_bytes_per_launch": ntt_bytes / ntt_launch,
                         "launches_per_step": ntt_launch,
                         "measured": "HIP events around every launch, median of %d serial passes of run() after a warm-up (one stream; the "

@@ -102,8 +102,8 @@ void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_
 void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
                     const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride = 0, u32 h0 = 0, u32 hn = 0, u32 nq = 1,
                     u32 q = 0);
-// Stage A of a batch of nq <= PIEHIP_MAX_BATCH queries on one database: acc[b][nq][K][2][L][N]; the database is read once for
-// the batch where the column-accumulator kernel applies (small_moduli, nq <= 4)
+// Stage A of a batch of nq <= STAGE_A_MAX_QUERIES queries on one database: acc[b][nq][K][2][L][N].  Where the column-accumulator
+// kernel applies (small_moduli) the queries go through it in groups of two to four, each group reading the database once
 static const u32 STAGE_A_MAX_QUERIES = 8;
 struct StageAQueries {
     const u64 *idx[STAGE_A_MAX_QUERIES];
