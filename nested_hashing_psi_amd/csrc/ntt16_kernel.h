@@ -203,29 +203,36 @@ __device__ __forceinline__ void row_put(const u64 *x, int r, u64 *p)
         *p = x[r];
     }
 }
-// the slice's way out to HBM
+// Global-memory accesses of the slice itself: through pointers in the GLOBAL address space.  The item loop makes the slice base
+// opaque (a scalar pair, see the kernel), and with that the compiler no longer knows which address space a derived pointer is in:
+// it would emit FLAT loads and stores, which also count in lgkmcnt -- every wait for an LDS read or a scalar twiddle load behind
+// one then waits for HBM.
+// (Non-temporal loads / stores of the slices, per launch site, were measured in r04: the transforms get 3-6 % shorter and the
+// kernels that consume their output -- which then find nothing in the memory-side cache -- longer by the same microseconds.)
+typedef __attribute__((address_space(1))) u64 g_u64;
+typedef __attribute__((address_space(1))) u64x2 g_u64x2;
+__device__ __forceinline__ u64x2 pair_get_global(const u64 *p) { return *(const g_u64x2 *)p; }
+__device__ __forceinline__ void pair_put_global(u64x2 v, u64 *p) { *(g_u64x2 *)p = v; }
 template <u32 CPT>
 __device__ __forceinline__ void row_put_global(const u64 *x, int r, u64 *p)
 {
-#ifdef NTT16_NT_STORES
     if (CPT == 2) {
         u64x2 v;
         v.x = x[2 * r], v.y = x[2 * r + 1];
-        __builtin_nontemporal_store(v, reinterpret_cast<u64x2 *>(p));
+        pair_put_global(v, p);
     } else {
-        __builtin_nontemporal_store(x[r], p);
+        *(g_u64 *)p = x[r];
     }
-#else
-    row_put<CPT>(x, r, p);
-#endif
 }
-__device__ __forceinline__ void pair_put_global(u64x2 v, u64 *p)
+template <u32 CPT>
+__device__ __forceinline__ void row_get_global(u64 *x, int r, const u64 *p)
 {
-#ifdef NTT16_NT_STORES
-    __builtin_nontemporal_store(v, reinterpret_cast<u64x2 *>(p));
-#else
-    *reinterpret_cast<u64x2 *>(p) = v;
-#endif
+    if (CPT == 2) {
+        const u64x2 v = pair_get_global(p);
+        x[2 * r] = v.x, x[2 * r + 1] = v.y;
+    } else {
+        x[r] = *(const g_u64 *)p;
+    }
 }
 
 // DS operations of one wave execute in issue order: a hand-off inside the wave only needs the compiler kept from
@@ -337,6 +344,9 @@ inline u32 lane_to_std(u32 p) { return lane_to_std_t(p, T); }
 #define NTT16_PRIO_F(i) NTT16_PASS_PRIO(NTT16_PRIO_PICK(i, NTT16_PF))
 #define NTT16_PRIO_I(i) NTT16_PASS_PRIO(NTT16_PRIO_PICK(i, NTT16_PI))
 
+#ifndef NTT16_LIFT_XCD
+#define NTT16_LIFT_XCD 1
+#endif
 // LIFT (forward only): the launch may carry key-switch digit items (Args::lift_first); a separate instantiation, so that the
 // plain forward transform does not pay for the lift's registers
 template <u32 LOGNS, bool INV, bool LIFT = false>
@@ -379,7 +389,16 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
         const u32 coffb = 8 * CPT * tau_;  // ... and of the row accesses 1024 r + CPT tau (pass 1)
         const u32 lab = 4 * (tau_ & 60), lb = 16 * (tau_ & 63);  // ... and into the kernel-ordered twiddle tables of passes 3 (16 la) and 4 (16 l)
         const bool lift = LIFT && !INV && item >= a.lift_first;
-        const u32 item_l = lift ? item - a.lift_first : item;
+        // The lift_L * 2^s0 digit items of one (ciphertext, source limb) read the same source limb.  Consecutive workgroups sit on
+        // consecutive XCDs, each with its own L2: dealt in order, every XCD fetches every source limb from HBM.  Transposing each
+        // block of 64 items (8 x 8) hands the items that share a source to workgroups 8 apart -- one XCD, one fetch, seven L2 hits.
+        u32 item_l = item;
+        if (lift) {
+            item_l = item - a.lift_first;
+#if NTT16_LIFT_XCD
+            if ((item_l | 63) < a.nitems - a.lift_first) item_l = (item_l & ~63u) | ((item_l & 7) << 3) | ((item_l >> 3) & 7);
+#endif
+        }
         const u32 blk = item_l & ((1u << a.s0) - 1);
         const u32 limb = lift ? item_l >> a.s0 : limb_of(item);
         // (uniform; laundered through a scalar register pair so that the slice's addresses stay "scalar base + lane offset": left to
@@ -443,8 +462,8 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                     u64 y[16];  // the other half of the limb
 #pragma unroll
                     for (int r = 0; r < (int)R; r++) {
-                        row_get<CPT>(x, r, at_bytes(src + 1024 * r, coffb));
-                        row_get<CPT>(y, r, at_bytes(src + NS + 1024 * r, coffb));
+                        row_get_global<CPT>(x, r, at_bytes(src + 1024 * r, coffb));
+                        row_get_global<CPT>(y, r, at_bytes(src + NS + 1024 * r, coffb));
                     }
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
@@ -454,13 +473,13 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < (int)R; r++) row_get<CPT>(x, r, at_bytes(src + 1024 * r, coffb));
+                    for (int r = 0; r < (int)R; r++) row_get_global<CPT>(x, r, at_bytes(src + 1024 * r, coffb));
 #pragma unroll
                     for (int k = 0; k < 16; k++) x[k] = lift1(x[k]);
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < (int)R; r++) row_get<CPT>(x, r, at_bytes(g + 1024 * r, coffb));
+                for (int r = 0; r < (int)R; r++) row_get_global<CPT>(x, r, at_bytes(g + 1024 * r, coffb));
             }
             NTT16_PRIO_F(1);
 #pragma unroll
@@ -566,16 +585,14 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
             NTT16_STAMP(7);
             // ---- lane-ordered store -------------------------------------------------------------------------------------------
             const bool lazy = (a.flags & F_LAZY_OUT) != 0 && !lift;  // the key-switch MAC splits canonical digits into 30-bit halves
+            if (!lazy) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) x[k] = csub_neg(csub_neg(csub_neg(x[k], 0 - q4), 0 - q2), 0 - q);
+            }
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                u64 r0 = x[2 * j], r1 = x[2 * j + 1];
-                if (!lazy) {
-                    r0 = csub_neg(csub_neg(csub_neg(r0, 0 - q4), 0 - q2), 0 - q);
-                    r1 = csub_neg(csub_neg(csub_neg(r1, 0 - q4), 0 - q2), 0 - q);
-                }
                 u64x2 v;
-                v.x = r0;
-                v.y = r1;
+                v.x = x[2 * j], v.y = x[2 * j + 1];
                 pair_put_global(v, at_bytes(g + 2 * T * j, voffb));
             }
             NTT16_STAMP(8);
@@ -593,7 +610,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                 const u64 *gw = g + 1024 * w;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const u64x2 v = *reinterpret_cast<const u64x2 *>(at_bytes(gw + 128 * j, lb));
+                    const u64x2 v = pair_get_global(at_bytes(gw + 128 * j, lb));
                     yv[2 * j] = v.x, yv[2 * j + 1] = v.y;
                 }
                 // (the image is free: every wave passed the barrier behind the previous slice's pass-1' reads)
@@ -622,17 +639,15 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
                         u64x2 v;
-                        v.x = x[2 * j];
-                        v.y = x[2 * j + 1];
-                        *reinterpret_cast<u64x2 *>(at_bytes(co + 2 * T * j, voffb)) = v;
+                        v.x = x[2 * j], v.y = x[2 * j + 1];
+                        pair_put_global(v, at_bytes(co + 2 * T * j, voffb));
                     }
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const u64x2 v = *reinterpret_cast<const u64x2 *>(at_bytes(g + 2 * T * j, voffb));
-                    x[2 * j] = v.x;
-                    x[2 * j + 1] = v.y;
+                    const u64x2 v = pair_get_global(at_bytes(g + 2 * T * j, voffb));
+                    x[2 * j] = v.x, x[2 * j + 1] = v.y;
                 }
             }
             NTT16_FENCE();

@@ -222,33 +222,58 @@ int main(int argc, char **argv)
     if (sizes.empty()) sizes = {224, 448, 512, 756, 784, 1024, 2048, 4096};
     // inv = 2: the run()'s first inverse launch -- standard order in (stage A's accumulators), the lane-ordered copy of the X
     // operand's limbs written on the side (K = 2 ciphertexts of 2 x 3 limbs per row; rows of 12 limbs)
-    for (int inv = 0; inv < 3; inv++)
+    // LAB_ROT=n: the launches cycle through n buffer sets (beyond the 256 MiB of the memory-side cache: every launch streams from HBM,
+    // as in run(), instead of finding the previous launch's output)
+    const int nrot = getenv("LAB_ROT") ? atoi(getenv("LAB_ROT")) : 1;
+    // inv = 2: the run()'s first inverse launch -- standard order in (stage A's accumulators), the lane-ordered copy of the X
+    // operand's limbs written on the side (K = 2 ciphertexts of 2 x 3 limbs per row; rows of 12 limbs)
+    // inv = 3: the run()'s last forward launch -- a third plain items (d0, d1), two thirds key-switch digits lifted in the load phase
+    for (int inv = 0; inv < 4; inv++)
         for (u32 nitems : sizes) {
-            u64 *d, *d_copy = nullptr;
-            CK(hipMalloc((void **)&d, (size_t)nitems * NS * 8));
-            CK(hipMemset(d, 1, (size_t)nitems * NS * 8));
+            std::vector<u64 *> d(nrot), d_copy(nrot, nullptr), d_src(nrot, nullptr);
             Args a;
             memset(&a, 0, sizeof(a));
-            a.data = d, a.twp = (const u64x2 *)d_twp, a.twk = (const u64x2 *)d_twk, a.dc = d_dc, a.N = N, a.s0 = s0, a.nitems = nitems;
+            a.twp = (const u64x2 *)d_twp, a.twk = (const u64x2 *)d_twk, a.dc = d_dc, a.N = N, a.s0 = s0, a.nitems = nitems;
             a.mod_base = 0, a.mod_count = nmod;
-            a.flags = inv ? F_FOLDED : F_LAZY_OUT;
+            a.flags = (inv == 1 || inv == 2) ? F_FOLDED : F_LAZY_OUT;
+            a.lift_first = ~0u;
+            const size_t rows = ((nitems >> s0) + 4 * nmod - 1) / (4 * nmod);
+            u32 nlift_rows = 0;
             if (inv == 2) {
                 a.flags |= F_STD_IN;
                 a.copy_K = 2, a.copy_L = nmod, a.copy_M = 2 * nmod + 1;
-                const size_t rows = ((nitems >> s0) + 4 * nmod - 1) / (4 * nmod);
-                CK(hipMalloc((void **)&d_copy, rows * 4 * a.copy_M * N * 8));
-                a.copy_out = d_copy;
+            }
+            if (inv == 3) {
+                // nb ciphertexts: 2 L plain limbs and L * L digit limbs each
+                const u32 per = (2 * nmod + nmod * nmod) << s0;
+                nlift_rows = (nitems + per - 1) / per;
+                a.lift_first = nlift_rows * ((2 * nmod) << s0);
+                if (a.lift_first > nitems) a.lift_first = nitems;
+                a.lift_L = nmod, a.lift_stride = (size_t)nmod * N;
+            }
+            for (int r = 0; r < nrot; r++) {
+                CK(hipMalloc((void **)&d[r], (size_t)nitems * NS * 8));
+                CK(hipMemset(d[r], 1, (size_t)nitems * NS * 8));
+                if (inv == 2) CK(hipMalloc((void **)&d_copy[r], rows * 4 * a.copy_M * N * 8));
+                if (inv == 3) {
+                    CK(hipMalloc((void **)&d_src[r], (size_t)(nlift_rows + 1) * nmod * N * 8));
+                    CK(hipMemset(d_src[r], 1, (size_t)(nlift_rows + 1) * nmod * N * 8));
+                }
             }
             const u32 grid = nitems < LAB_SLOTS ? nitems : LAB_SLOTS;
-            a.lift_first = ~0u;
             hipEvent_t e0, e1;
             CK(hipEventCreate(&e0));
             CK(hipEventCreate(&e1));
             const int iters = 20;
             for (int it = 0; it < iters + 3; it++) {
                 if (it == 3) CK(hipEventRecord(e0, 0));
-                if (inv)
+                const int r = it % nrot;
+                a.data = d[r], a.copy_out = d_copy[r];
+                if (inv == 3) a.data2 = d[r] + (size_t)a.lift_first * NS, a.lift_src = d_src[r];
+                if (inv == 1 || inv == 2)
                     hipLaunchKernelGGL((ntt16_kernel_t<LAB_LOGNS, true>), dim3(grid), dim3(T), lds, 0, a);
+                else if (inv == 3)
+                    hipLaunchKernelGGL((ntt16_kernel_t<LAB_LOGNS, false, true>), dim3(grid), dim3(T), lds, 0, a);
                 else
                     hipLaunchKernelGGL((ntt16_kernel_t<LAB_LOGNS, false>), dim3(grid), dim3(T), lds, 0, a);
             }
@@ -257,10 +282,14 @@ int main(int argc, char **argv)
             float ms;
             CK(hipEventElapsedTime(&ms, e0, e1));
             const double us = ms * 1e3 / iters;
-            printf("%s nitems=%5u  %8.2f us/launch  %6.2f slices/us  %7.1f GB/s alg (%.3f of 8 TB/s)\n", inv == 2 ? "inv std-in + copy" : inv ? "inv" : "fwd", nitems, us,
+            static const char *names[4] = {"fwd", "inv", "inv std-in + copy", "fwd + digit lift"};
+            printf("%s nitems=%5u  %8.2f us/launch  %6.2f slices/us  %7.1f GB/s alg (%.3f of 8 TB/s)\n", names[inv], nitems, us,
                    nitems / us, 16.0 * NS * nitems / (us * 1e-6) / 1e9, 16.0 * NS * nitems / (us * 1e-6) / 8e12);
-            CK(hipFree(d));
-            if (d_copy) CK(hipFree(d_copy));
+            for (int r = 0; r < nrot; r++) {
+                CK(hipFree(d[r]));
+                if (d_copy[r]) CK(hipFree(d_copy[r]));
+                if (d_src[r]) CK(hipFree(d_src[r]));
+            }
         }
     return 0;
 }
