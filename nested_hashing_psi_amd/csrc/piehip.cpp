@@ -126,6 +126,10 @@ void enqueue_keyswitch(piehip_ctx *h, MulWs &w, u32 nb, const u64 *key, const u6
     {
         // the result buffer may still be read by work the caller queued on the handle's stream before this run
         if (h->wait_before_results && out_is_result) (void)hipStreamWaitEvent(h->stream, h->wait_before_results, 0);
+        if (h->chain_armed && out_is_result) {  // the next queue group of a host-results run may start (piehip_run_into)
+            h->chain_armed = false;
+            (void)hipEventRecord(h->ev_chain, h->stream);
+        }
         ProfScope ps(h, PIEHIP_K_RELIN, W * (nb * ((double)L * L + 2 * L + 2 * L + (mask ? L : 0)) + 2.0 * L * L));
         launch_relin_mac(h->d_dc, N, L, w.d01, 2 * LN, w.dig, key, mask, out, nb, h->stream,
                          (sigma && h->sigma_on) ? h->d_sigma_inv : nullptr, key_stride, key_group,
@@ -421,6 +425,7 @@ int piehip_destroy(piehip_handle h)
     drop_graph(h);
     free_host_path(h);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_chain) (void)hipEventDestroy(h->ev_chain);
     for (hipEvent_t e : h->ev_join) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1132,8 +1137,7 @@ namespace piehip {
 u32 run_group_size(u32 b, u32 ng, u32 g)
 {
     if (ng == 2) {
-        u32 first = (4 * b + 3) / 7;
-        if (const char *lab = getenv("PIEHIP_LAB_SPLIT")) first = std::min<u32>(b - 1, std::max(1, atoi(lab)));   // lab sweep
+        const u32 first = (4 * b + 3) / 7;
         return g == 0 ? first : b - first;
     }
     return b / ng + (g < b % ng ? 1 : 0);
@@ -1314,7 +1318,21 @@ int piehip_run_into(piehip_handle h, void *d_results)
             if (h->inputs_dirty) HIPCHK(hipStreamWaitEvent(h->side_streams[g], h->ev_fork, 0));
             h->stream = h->side_streams[g];
             h->wait_before_results = h->inputs_dirty ? nullptr : h->ev_fork;
+            // Results go down to host memory (piehip_run_staged / piehip_run_host*): the groups do not run side by side but one
+            // behind the other -- group g + 1 starts when group g has only its result-writing kernel left, and the download of
+            // group g (8 of 14 MiB at C3) travels under the evaluation of group g + 1.  Results in host memory after 0.53 ms
+            // instead of 0.60 at C3, 1.30 instead of 1.50 for a batch of three; a stream of queries over several handles is
+            // bound by the uploads either way (profiles/r04/online_phase_staggered_groups.txt).
+            if (h->host_results && g > 0) HIPCHK(hipStreamWaitEvent(h->side_streams[g], h->ev_chain, 0));
+            if (h->host_results && g + 1 < ng) {
+                if (!h->ev_chain) HIPCHK(hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming));
+                h->chain_armed = true;
+            }
             enqueue_run_bins(h, b0, nb, (u64 *)d_results);
+            if (h->chain_armed) {  // a chain without a key switch (K = 1): behind all of it
+                h->chain_armed = false;
+                HIPCHK(hipEventRecord(h->ev_chain, h->side_streams[g]));
+            }
             if (h->host_results) HIPCHK(download_rows(h, (const u64 *)d_results, b0, nb));  // this group's slice, on this group's queue
             HIPCHK(hipEventRecord(h->ev_join[g], h->side_streams[g]));
             b0 += nb;

@@ -88,6 +88,10 @@ struct piehip_ctx {
     std::vector<hipStream_t> side_streams;        // extra queues of run(): one group of bin layers each (see piehip_run)
     std::vector<hipEvent_t> ev_join;
     hipEvent_t ev_fork = nullptr;
+    // runs that bring their results down to host memory: queue group g + 1 starts when group g has reached the kernel that writes
+    // its results, so that the download of group g runs under the evaluation of group g + 1 (piehip_run_into)
+    hipEvent_t ev_chain = nullptr;
+    bool chain_armed = false;                     // set while such a group is enqueued: recorded in front of its result-writing kernel
     u32 run_streams = 0;                          // piehip_set_run_streams: 0 = all queues
     bool inputs_dirty = true;                     // inputs / keys / database changed on the handle's stream since the last run()
     hipEvent_t wait_before_results = nullptr;     // set while run() enqueues a group: its result-writing kernel waits for this

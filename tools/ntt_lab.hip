@@ -66,8 +66,12 @@ static u64 mulmod_h(u64 a, u64 b, u64 q) { return (u64)((unsigned __int128)a * b
 
 int main(int argc, char **argv)
 {
-    const u32 s0 = 1, N = NS << s0, nmod = 3;
-    const u64 qs[3] = {(1ULL << 60) - 33 * 32768 + 1, (1ULL << 60) - 97 * 32768 + 1, (1ULL << 59) + 5 * 32768 + 1};
+#ifndef LAB_NMOD
+#define LAB_NMOD 3   // moduli the limbs cycle over: 4 = the run's Q launches (one table per XCD), 9 = its QP launches
+#endif
+    const u32 s0 = 1, N = NS << s0, nmod = LAB_NMOD;
+    u64 qs[LAB_NMOD < 3 ? 3 : LAB_NMOD] = {(1ULL << 60) - 33 * 32768 + 1, (1ULL << 60) - 97 * 32768 + 1, (1ULL << 59) + 5 * 32768 + 1};
+    for (u32 m = 3; m < nmod; m++) qs[m] = (1ULL << 60) - (161 + 64 * (u64)m) * 32768 + 1;
     static DevConsts dc;
     memset(&dc, 0, sizeof(dc));
     for (u32 m = 0; m < nmod; m++) dc.mod[m].q = qs[m];
