@@ -853,6 +853,8 @@ def main():
         for name in passes[0]:
             recs = sorted((p_[name] for p_ in passes if name in p_), key=lambda r_: r_["ms"])
             agg[name] = dict(recs[len(recs) // 2])
+        pair = agg.pop("event_pair", None)   # the bracket itself: two events back to back, once per queue group of a pass
+        pair_us = 1e3 * pair["ms"] / pair["launches"] if pair and pair["launches"] else None
         for name, a in agg.items():
             kernels[name] = dict(launches_per_step=a["launches"], us_per_step=1e3 * a["ms"],
                                  alg_GBps=a["alg_bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else None)
@@ -867,6 +869,10 @@ def main():
                                           "FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run",
                         "avg_launch_us": 1e3 * ntt_ms / ntt_launch, "alg_bytes_per_launch": ntt_bytes / ntt_launch,
                         "launches_per_step": ntt_launch,
+                        # what the bracket reads with no launch inside it; rocprofv3's kernel durations (profiles/) do not contain it
+                        "event_pair_us": pair_us,
+                        "frac_net_of_event_pair": (ntt_bytes / ((ntt_ms - 1e-3 * pair_us * ntt_launch) * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                   if pair_us is not None and ntt_ms > 1e-3 * pair_us * ntt_launch else None),
                         "measured": "HIP events around every launch, median of %d serial passes of run() after a warm-up (one stream; the "
                                     "timed region uses %s)" % (len(passes), "%d queue(s) per run(), %d quer%s per run(), %d run() in flight"
                                                               % (run_streams or 2, batch, "y" if batch == 1 else "ies", in_flight))}

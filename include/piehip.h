@@ -338,7 +338,7 @@ int piehip_client_decrypt(piehip_handle h, const uint64_t *sk, const uint64_t *c
  * With profiling on, run() brackets every kernel launch with HIP events on the handle's stream.
  * piehip_profile_read returns, per kernel class, the launch count, total milliseconds, and the
  * algorithmic bytes (SURVEY.md 8d formulas) of the last run. */
-#define PIEHIP_NKERNELS 12
+#define PIEHIP_NKERNELS 13
 enum {
     PIEHIP_K_STAGE_A = 0,   /* fused ct x pt multiply-accumulate + minus add  (A3+A4)          */
     PIEHIP_K_NTT_FWD = 1,   /* forward negacyclic NTT                          (A1)             */
@@ -351,7 +351,8 @@ enum {
     PIEHIP_K_MASK = 8,      /* final ct x pt mask multiply when not fused                       */
     PIEHIP_K_ENCODE = 9,    /* packed encoding                                 (A2)             */
     PIEHIP_K_AUTOMORPH = 10,/* automorphism permutation                        (A9)             */
-    PIEHIP_K_OTHER = 11
+    PIEHIP_K_OTHER = 11,
+    PIEHIP_K_EVENT_PAIR = 12 /* no launch: the two events of a bracket back to back -- what the bracket itself reads on this stream */
 };
 /* times `iters` back-to-back NTT launches over nlimbs random limbs (moduli cycle over mod_count from 0);
  * flags: bit 0 = inverse transform, bit 1 = EVALUATION side in the library's internal lane order.

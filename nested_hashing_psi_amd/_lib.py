@@ -11,7 +11,7 @@ u32p = C.POINTER(C.c_uint32)
 i32p = C.POINTER(C.c_int32)
 f64p = C.POINTER(C.c_double)
 
-NKERNELS = 12
+NKERNELS = 13
 
 # every symbol include/piehip.h declares: (restype, argtypes)
 SYMBOLS = {

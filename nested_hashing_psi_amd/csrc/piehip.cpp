@@ -36,7 +36,8 @@ void drop_graph(piehip_ctx *h)
 
 }  // namespace piehip
 static const char *KNAMES[PIEHIP_NKERNELS] = {"stage_a_mac", "ntt_fwd", "ntt_inv",  "expand",   "tensor",    "scale_round",
-                                              "digits",      "relin",   "mask_mul", "encode",   "automorph", "other"};
+                                              "digits",      "relin",   "mask_mul", "encode",   "automorph", "other",
+                                              "event_pair"};
 namespace piehip {
 
 // ---- profiling helpers -------------------------------------------------------------------------
@@ -1172,6 +1173,9 @@ static void enqueue_run_bins(piehip_ctx *h, u32 b0, u32 nb, u64 *results)
     } mask_div_scope{h};
     h->mask_div = nq;
     h->key_group = (nq > 1 && h->d_evkq && h->evkq_n == nq) ? nq : 1;  // per-query EvalMult keys: row r of a group is query r % nq
+    if (h->profiling) {  // an empty bracket: what the event pair itself costs on this stream (reported beside the kernels' times)
+        ProfScope ps(h, PIEHIP_K_EVENT_PAIR, 0.0);
+    }
     {   // stage A: all inner products of these bin layers in one launch (BatchedFHEHIPPIE.cpp:101-116)
         ProfScope ps(h, PIEHIP_K_STAGE_A, W * ((double)layers * K * E * L + nq * ((double)K * E * 2 * L + 2.0 * L + (double)layers * K * 2 * L)));
         StageAQueries qs = {};
