@@ -389,14 +389,15 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
         const u32 coffb = 8 * CPT * tau_;  // ... and of the row accesses 1024 r + CPT tau (pass 1)
         const u32 lab = 4 * (tau_ & 60), lb = 16 * (tau_ & 63);  // ... and into the kernel-ordered twiddle tables of passes 3 (16 la) and 4 (16 l)
         const bool lift = LIFT && !INV && item >= a.lift_first;
-        // The lift_L * 2^s0 digit items of one (ciphertext, source limb) read the same source limb.  Consecutive workgroups sit on
-        // consecutive XCDs, each with its own L2: dealt in order, every XCD fetches every source limb from HBM.  Transposing each
-        // block of 64 items (8 x 8) hands the items that share a source to workgroups 8 apart -- one XCD, one fetch, seven L2 hits.
+        // The G = lift_L * 2^s0 digit items of one (ciphertext, source limb) read the same source limb.  Consecutive workgroups sit
+        // on consecutive XCDs, each with its own L2: dealt in order, every XCD fetches every source limb from HBM.  Transposing each
+        // block of 8 G items (8 x G) hands the items that share a source to workgroups 8 apart -- one XCD, one fetch, G - 1 L2 hits.
         u32 item_l = item;
         if (lift) {
             item_l = item - a.lift_first;
 #if NTT16_LIFT_XCD
-            if ((item_l | 63) < a.nitems - a.lift_first) item_l = (item_l & ~63u) | ((item_l & 7) << 3) | ((item_l >> 3) & 7);
+            const u32 G = a.lift_L << a.s0, blk8 = 8 * G, within = item_l % blk8;
+            if (item_l - within + blk8 <= a.nitems - a.lift_first) item_l = item_l - within + (within & 7) * G + (within >> 3);
 #endif
         }
         const u32 blk = item_l & ((1u << a.s0) - 1);
