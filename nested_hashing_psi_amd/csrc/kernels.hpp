@@ -53,6 +53,8 @@ struct NttExtra {
     u32 skip_L = 0, skip_M = 0;
     bool lazy_out = false;  // forward, lane order: leave the residues in [0, 8q) (the consumer reduces anyway)
     bool folded = false;    // set by launch_ntt(.., folded): inverse transforms then hand over unnormalised [0, 4q) residues
+    bool x_lane_in = false; // 16-coefficient kernel, inverse, standard order in: the operand-0 polynomials are READ, lane-ordered, from
+                            // where copy_out would have put them (stage A wrote them there: StageAXOut) and nothing is copied
 };
 // The 16-coefficients-per-thread kernel (ntt16_kernel.h, kernels_ntt16.hip) for slices of 2^13 and 2^14 coefficients: every transform whose
 // EVALUATION side is in lane order, and every inverse transform.  Its lane order differs from the 32-coefficient kernel's:
@@ -99,9 +101,17 @@ void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_
 // bstride: bin-layer count of the database array db[K][bstride][E][L][N] when only b <= bstride layers (starting at the
 // layer db points to) are evaluated; 0 = b.  h0, hn: only the inner hash functions [h0, h0 + hn) (hn = 0: all from h0)
 // nq, q: the accumulators are row q of a batch of nq queries, acc[b][nq][K][2][L][N] (nq = 1: the layout above)
+// xo (column-accumulator kernels only): the accumulators of inner hash function 0 -- operand X of the first ciphertext product --
+// are not written to acc but, lane-ordered (ntt16_kernel.h), into the Q limbs of the QP operand array xo->out[row][4][M][N],
+// slots 0, 1: where the tensor product reads them.  The inverse transform then takes them from there (NttExtra::x_lane_in)
+// instead of writing that copy itself.
+struct StageAXOut {
+    u64 *out = nullptr;
+    u32 M = 0, logns = 0;  // limbs per polynomial of the QP array; log2 of the transform's slice length
+};
 void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
                     const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride = 0, u32 h0 = 0, u32 hn = 0, u32 nq = 1,
-                    u32 q = 0);
+                    u32 q = 0, const StageAXOut *xo = nullptr);
 // Stage A of a batch of nq <= STAGE_A_MAX_QUERIES queries on one database: acc[b][nq][K][2][L][N].  Where the column-accumulator
 // kernel applies (small_moduli) the queries go through it in groups of two to four, each group reading the database once
 static const u32 STAGE_A_MAX_QUERIES = 8;
@@ -110,7 +120,8 @@ struct StageAQueries {
     const u64 *minus[STAGE_A_MAX_QUERIES];
 };
 void launch_stage_a_batch(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const StageAQueries &qs, u32 nq, const u64 *db,
-                          u64 *acc, hipStream_t st, bool small_moduli, u32 bstride = 0, u32 h0 = 0, u32 hn = 0);
+                          u64 *acc, hipStream_t st, bool small_moduli, u32 bstride = 0, u32 h0 = 0, u32 hn = 0,
+                          const StageAXOut *xo = nullptr);
 
 // (per-host-thread switch, set from the context before its launches: all Q and P moduli lie in (2^59, 2^60), which lets
 // the base-conversion and key-switch kernels use the carry-free v_mad_u64_u32 column accumulators and one-word Barrett)

@@ -67,6 +67,7 @@ bool launch_ntt16(const NttPlan &pl, bool folded, u64 *data, u32 nlimbs, u32 mod
     a.flags = 0;
     if (inverse && !sigma) a.flags |= ntt16::F_STD_IN;
     if (inverse && folded) a.flags |= ntt16::F_FOLDED;
+    if (inverse && !sigma && ex && ex->copy_out && ex->x_lane_in) a.flags |= ntt16::F_X_LANE_IN;
     if (!inverse && ex && ex->lazy_out) a.flags |= ntt16::F_LAZY_OUT;
     a.skip_L = (ex && !inverse) ? ex->skip_L : 0;
     a.skip_M = ex ? ex->skip_M : 0;

@@ -123,6 +123,14 @@ __global__ void __launch_bounds__(TPB) stage_a_kernel(const DevConsts *__restric
 // runs this kernel over a rotation of databases (every launch from HBM): 49 us for the 196 MiB of the headline workload
 // with seven layers per thread (168 registers, three waves per SIMD), the same with 16-byte lanes and one term ahead, 63 us
 // when it is forced to four waves per SIMD (spills) -- and 35 us for a plain read of the same bytes.
+// Lane-ordered home of coefficient n of a limb (ntt16_kernel.h: slices of 2^logns coefficients, T = 2^logns / 16 threads, thread tau
+// holds elements 16 tau .. 16 tau + 15 and stores pair j at 2 (T j + tau)): the offset inside the limb
+__device__ __forceinline__ u32 lane_home(u32 n, u32 logns)
+{
+    const u32 ns = 1u << logns, e = n & (ns - 1);
+    return (n & ~(ns - 1)) + 2 * ((ns >> 4) * ((e >> 1) & 7) + (e >> 4)) + (e & 1);
+}
+
 static const int SA_DEPTH = 4;
 template <bool W124>
 __device__ __forceinline__ u64 colacc_reduce(const ColAcc &a, const Mod &m, u64 nq);  // (instruction block, defined below)
@@ -130,7 +138,7 @@ template <int BPT>
 __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
                                                           const u64 *__restrict__ idx, const u64 *__restrict__ minus,
                                                           const u64 *__restrict__ db, u64 *__restrict__ acc, u32 bstride, u32 h0,
-                                                          u32 nq, u32 q)
+                                                          u32 nq, u32 q, StageAXOut xo)
 {
     const u32 nl = threadIdx.x;  // lane part of the coefficient index: every stream is a uniform base plus this
     const u32 n = blockIdx.x * TPB + nl;
@@ -188,10 +196,16 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
     }
 #pragma unroll
     for (int t = 0; t < BPT; t++) {
-        u64 *po = acc + ((((size_t)(beta0 + t) * nq + q) * K + h) * 2) * LN + (size_t)l * N + n;
+        const size_t row = (size_t)(beta0 + t) * nq + q;
+        u64 *po = acc + ((row * K + h) * 2) * LN + (size_t)l * N + n;
+        size_t cstride = LN;
+        if (h == 0 && xo.out) {  // operand X of the first product: straight to the QP operand array, lane-ordered (StageAXOut)
+            po = xo.out + ((row * 4) * xo.M + l) * N + lane_home(n, xo.logns);
+            cstride = (size_t)xo.M * N;
+        }
 #pragma unroll
         for (int c = 0; c < 2; c++)
-            po[(size_t)c * LN] = addmod(colacc_reduce<true>(a[t][c], m, 0 - m.q), minus[(size_t)c * LN + (size_t)l * N + n], m.q);
+            po[(size_t)c * cstride] = addmod(colacc_reduce<true>(a[t][c], m, 0 - m.q), minus[(size_t)c * LN + (size_t)l * N + n], m.q);
     }
 }
 
@@ -206,7 +220,7 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
 template <int BPT, int Q, int DEPTH>
 __global__ void __launch_bounds__(TPB) stage_a_mad_batch_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
                                                                 StageAQueries qs, const u64 *__restrict__ db, u64 *__restrict__ acc,
-                                                                u32 bstride, u32 h0, u32 nq, u32 q0, u32 tiles)
+                                                                u32 bstride, u32 h0, u32 nq, u32 q0, u32 tiles, StageAXOut xo)
 {
     StageATile tl;
     if (!stage_a_tile((N + TPB - 1) / TPB, L, tiles, b / BPT, tl)) return;
@@ -276,9 +290,15 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_batch_kernel(const DevConsts 
         for (int c = 0; c < 2; c++) mi[c] = qs.minus[q][(size_t)c * LN + (size_t)l * N + n];
 #pragma unroll
         for (int t = 0; t < BPT; t++) {
-            u64 *po = acc + ((((size_t)(beta0 + t) * nq + q0 + q) * K + h) * 2) * LN + (size_t)l * N + n;
+            const size_t row = (size_t)(beta0 + t) * nq + q0 + q;
+            u64 *po = acc + ((row * K + h) * 2) * LN + (size_t)l * N + n;
+            size_t cstride = LN;
+            if (h == 0 && xo.out) {  // operand X of the first product: straight to the QP operand array, lane-ordered (StageAXOut)
+                po = xo.out + ((row * 4) * xo.M + l) * N + lane_home(n, xo.logns);
+                cstride = (size_t)xo.M * N;
+            }
 #pragma unroll
-            for (int c = 0; c < 2; c++) po[(size_t)c * LN] = addmod(colacc_reduce<true>(a[q][t][c], m, 0 - m.q), mi[c], m.q);
+            for (int c = 0; c < 2; c++) po[(size_t)c * cstride] = addmod(colacc_reduce<true>(a[q][t][c], m, 0 - m.q), mi[c], m.q);
         }
     }
 }
@@ -286,13 +306,13 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_batch_kernel(const DevConsts 
 // one launch over b bin layers whose count is a multiple of the per-thread layer count `bpt`
 static void launch_stage_a_uniform(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
                                    const u64 *db, u64 *acc, hipStream_t st, bool mad, u32 bstride, u32 h0, u32 hn, int bpt, u32 nq,
-                                   u32 q)
+                                   u32 q, StageAXOut xo)
 {
     const int cpt = mad ? 1 : 2;
     dim3 grid((N / cpt + TPB - 1) / TPB, L, hn * (b / bpt));
 #define SA(B_)                                                                                                       \
     do {                                                                                                             \
-        if (mad) hipLaunchKernelGGL(stage_a_mad_kernel<B_>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0, nq, q); \
+        if (mad) hipLaunchKernelGGL(stage_a_mad_kernel<B_>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0, nq, q, xo); \
         else hipLaunchKernelGGL(stage_a_kernel<B_>, grid, dim3(TPB), 0, st, dc, N, L, K, b, E, idx, minus, db, acc, bstride, h0, nq, q);  \
     } while (0)
     switch (bpt) {
@@ -309,8 +329,11 @@ static void launch_stage_a_uniform(const DevConsts *dc, u32 N, u32 L, u32 K, u32
 }
 
 void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const u64 *idx, const u64 *minus,
-                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride, u32 h0, u32 hn, u32 nq, u32 q)
+                    const u64 *db, u64 *acc, hipStream_t st, bool small_moduli, u32 bstride, u32 h0, u32 hn, u32 nq, u32 q,
+                    const StageAXOut *xop)
 {
+    StageAXOut xo;
+    if (xop && small_moduli) xo = *xop;  // (the 128-bit kernel keeps writing acc: callers check small_moduli before they rely on xo)
     if (!bstride) bstride = b;
     if (!hn) hn = K - h0;
     if (!nq) nq = 1;
@@ -329,13 +352,15 @@ void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, cons
     if (b <= cap) bpt = b;
     const size_t LN = (size_t)L * N;
     if (bpt) {
-        launch_stage_a_uniform(dc, N, L, K, b, E, idx, minus, db, acc, st, mad, bstride, h0, hn, (int)bpt, nq, q);
+        launch_stage_a_uniform(dc, N, L, K, b, E, idx, minus, db, acc, st, mad, bstride, h0, hn, (int)bpt, nq, q, xo);
         return;
     }
     const u32 full = (b / cap) * cap, rest = b - full;
-    launch_stage_a_uniform(dc, N, L, K, full, E, idx, minus, db, acc, st, mad, bstride, h0, hn, (int)cap, nq, q);
+    launch_stage_a_uniform(dc, N, L, K, full, E, idx, minus, db, acc, st, mad, bstride, h0, hn, (int)cap, nq, q, xo);
+    StageAXOut xr = xo;
+    if (xr.out) xr.out += (size_t)full * nq * 4 * xr.M * N;
     launch_stage_a_uniform(dc, N, L, K, rest, E, idx, minus, db + (size_t)full * E * LN, acc + (size_t)full * nq * K * 2 * LN, st, mad,
-                           bstride, h0, hn, (int)rest, nq, q);
+                           bstride, h0, hn, (int)rest, nq, q, xr);
 }
 
 // Stage A of a query batch: acc[b][nq][K][2][L][N].  Column-accumulator kernel (every modulus < 2^60): groups of two to four
@@ -343,26 +368,26 @@ void launch_stage_a(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, cons
 // otherwise one launch series per query.
 template <int Q, int BPT>
 static void launch_stage_a_batch_qb(const DevConsts *dc, u32 N, u32 L, u32 K, u32 nb, u32 E, const StageAQueries &qs, const u64 *db,
-                                    u64 *acc, hipStream_t st, u32 bstride, u32 h0, u32 hn, u32 nq, u32 q0)
+                                    u64 *acc, hipStream_t st, u32 bstride, u32 h0, u32 hn, u32 nq, u32 q0, StageAXOut xo)
 {
     const u32 nx = (N + TPB - 1) / TPB;
     constexpr int DEPTH = Q == 4 ? 2 : 3;  // terms in flight behind the one being accumulated (profiles/r03/stage_a_batch_microbench.txt)
     hipLaunchKernelGGL((stage_a_mad_batch_kernel<BPT, Q, DEPTH>), stage_a_grid(nx, L, hn, nb / BPT), dim3(TPB), 0, st, dc, N, L, K, nb, E,
-                       qs, db, acc, bstride, h0, nq, q0, nx * L * hn);
+                       qs, db, acc, bstride, h0, nq, q0, nx * L * hn, xo);
 }
 template <int Q>
 static void launch_stage_a_batch_q(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const StageAQueries &qs, const u64 *db,
-                                   u64 *acc, hipStream_t st, u32 bstride, u32 h0, u32 hn, u32 nq, u32 q0)
+                                   u64 *acc, hipStream_t st, u32 bstride, u32 h0, u32 hn, u32 nq, u32 q0, StageAXOut xo)
 {
     constexpr u32 cap = Q == 2 ? 4 : 2;  // bin layers per thread: Q * cap accumulator pairs (eight at most)
     const size_t LN = (size_t)L * N;
-    auto go = [&](u32 nb, u32 bpt, const u64 *dbp, u64 *accp) {
+    auto go = [&](u32 nb, u32 bpt, const u64 *dbp, u64 *accp, StageAXOut x) {
         if constexpr (cap >= 4) {
-            if (bpt == 4) return launch_stage_a_batch_qb<Q, 4>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0);
-            if (bpt == 3) return launch_stage_a_batch_qb<Q, 3>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0);
+            if (bpt == 4) return launch_stage_a_batch_qb<Q, 4>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0, x);
+            if (bpt == 3) return launch_stage_a_batch_qb<Q, 3>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0, x);
         }
-        if (bpt == 2) return launch_stage_a_batch_qb<Q, 2>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0);
-        return launch_stage_a_batch_qb<Q, 1>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0);
+        if (bpt == 2) return launch_stage_a_batch_qb<Q, 2>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0, x);
+        return launch_stage_a_batch_qb<Q, 1>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0, x);
     };
     u32 bpt = 0;
     for (u32 c = cap; c >= 2; c--)
@@ -371,14 +396,18 @@ static void launch_stage_a_batch_q(const DevConsts *dc, u32 N, u32 L, u32 K, u32
             break;
         }
     if (b <= cap) bpt = b;
-    if (bpt) return go(b, bpt, db, acc);
+    if (bpt) return go(b, bpt, db, acc, xo);
     const u32 full = (b / cap) * cap, rest = b - full;
-    go(full, cap, db, acc);
-    go(rest, rest, db + (size_t)full * E * LN, acc + (size_t)full * nq * K * 2 * LN);
+    go(full, cap, db, acc, xo);
+    StageAXOut xr = xo;
+    if (xr.out) xr.out += (size_t)full * nq * 4 * xr.M * N;
+    go(rest, rest, db + (size_t)full * E * LN, acc + (size_t)full * nq * K * 2 * LN, xr);
 }
 void launch_stage_a_batch(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const StageAQueries &qs, u32 nq, const u64 *db,
-                          u64 *acc, hipStream_t st, bool small_moduli, u32 bstride, u32 h0, u32 hn)
+                          u64 *acc, hipStream_t st, bool small_moduli, u32 bstride, u32 h0, u32 hn, const StageAXOut *xop)
 {
+    StageAXOut xo;
+    if (xop && small_moduli) xo = *xop;
     if (!bstride) bstride = b;
     if (!hn) hn = K - h0;
     u32 q0 = 0;
@@ -387,13 +416,13 @@ void launch_stage_a_batch(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E
         const u32 left = nq - q0, g = left == 5 || left == 6 ? 3 : std::min(left, 4u);
         StageAQueries sub = {};
         for (u32 q = 0; q < g; q++) sub.idx[q] = qs.idx[q0 + q], sub.minus[q] = qs.minus[q0 + q];
-        if (g == 2) launch_stage_a_batch_q<2>(dc, N, L, K, b, E, sub, db, acc, st, bstride, h0, hn, nq, q0);
-        else if (g == 3) launch_stage_a_batch_q<3>(dc, N, L, K, b, E, sub, db, acc, st, bstride, h0, hn, nq, q0);
-        else launch_stage_a_batch_q<4>(dc, N, L, K, b, E, sub, db, acc, st, bstride, h0, hn, nq, q0);
+        if (g == 2) launch_stage_a_batch_q<2>(dc, N, L, K, b, E, sub, db, acc, st, bstride, h0, hn, nq, q0, xo);
+        else if (g == 3) launch_stage_a_batch_q<3>(dc, N, L, K, b, E, sub, db, acc, st, bstride, h0, hn, nq, q0, xo);
+        else launch_stage_a_batch_q<4>(dc, N, L, K, b, E, sub, db, acc, st, bstride, h0, hn, nq, q0, xo);
         q0 += g;
     }
     for (; q0 < nq; q0++)
-        launch_stage_a(dc, N, L, K, b, E, qs.idx[q0], qs.minus[q0], db, acc, st, small_moduli, bstride, h0, hn, nq, q0);
+        launch_stage_a(dc, N, L, K, b, E, qs.idx[q0], qs.minus[q0], db, acc, st, small_moduli, bstride, h0, hn, nq, q0, xop);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -271,6 +271,7 @@ enum : u32 {
     F_STD_IN = 1,    // inverse: EVALUATION input in standard (bit-reversed) order instead of lane order
     F_LAZY_OUT = 2,  // forward: leave [0, 8q) residues (the consumer reduces anyway)
     F_FOLDED = 4,    // inverse: the consumer applies the outermost stage and N^-1: hand over [0, 4q) residues as they are
+    F_X_LANE_IN = 8, // inverse, standard order in: operand-0 polynomials come lane-ordered from copy_out's place instead (no copy)
 };
 
 // Host side: the twiddle pairs of passes 3 and 4 of one (modulus, direction) in kernel order, for every slice of a limb.
@@ -602,7 +603,17 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
             NTT16_STAMP(0);
             NTT16_PRIO_I(0);
             NTT16_LOAD4(t12, 4, 4);   // (the other four behind the data loads: the register budget is x 32 + twiddles)
-            if (a.flags & F_STD_IN) {
+            // operand-0 polynomials of a standard-order launch: their lane-ordered EVALUATION form lives in the Q limbs of the QP
+            // operand array -- written there by this launch (copy) or already by stage A (F_X_LANE_IN: read from there)
+            const bool is_x = (a.flags & F_STD_IN) && a.copy_out && (limb / (2 * a.copy_L)) % a.copy_K == 0;
+            u64 *co = nullptr;
+            if (is_x) {
+                const u32 bin = limb / (2 * a.copy_L * a.copy_K), cc = (limb / a.copy_L) & 1, i = limb % a.copy_L;
+                co = a.copy_out + (((((size_t)bin * 4 + cc) * a.copy_M + i) << a.s0) + blk) * NS;
+                asm("" : "+s"(co));
+            }
+            const bool x_in = is_x && (a.flags & F_X_LANE_IN);
+            if ((a.flags & F_STD_IN) && !x_in) {
                 // Standard order in.  A wave's pass-4' elements are the 1024 contiguous coefficients of its own block: it loads
                 // exactly those (coalesced: pair 64 j + l of the block per lane and instruction), drops them into its own region of
                 // the image and picks up its 16 contiguous coefficients -- a hand-off inside the wave.  (Until r04 the slice
@@ -632,11 +643,7 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                     x[2 * j] = v.x;
                     x[2 * j + 1] = v.y;
                 }
-                // operand-0 polynomials keep their EVALUATION form, lane-ordered, as the Q limbs of the QP operand array
-                if (a.copy_out && (limb / (2 * a.copy_L)) % a.copy_K == 0) {
-                    const u32 bin = limb / (2 * a.copy_L * a.copy_K), cc = (limb / a.copy_L) & 1, i = limb % a.copy_L;
-                    u64 *co = a.copy_out + (((((size_t)bin * 4 + cc) * a.copy_M + i) << a.s0) + blk) * NS;
-                    asm("" : "+s"(co));
+                if (is_x) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
                         u64x2 v;
@@ -645,9 +652,11 @@ __global__ void __launch_bounds__(Geo<LOGNS>::T, 4) ntt16_kernel_t(Args a)
                     }
                 }
             } else {
+                const u64 *src = x_in ? co : g;
+                asm("" : "+s"(src));
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const u64x2 v = pair_get_global(at_bytes(g + 2 * T * j, voffb));
+                    const u64x2 v = pair_get_global(at_bytes(src + 2 * T * j, voffb));
                     x[2 * j] = v.x, x[2 * j + 1] = v.y;
                 }
             }

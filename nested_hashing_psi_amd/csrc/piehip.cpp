@@ -1173,6 +1173,14 @@ static void enqueue_run_bins(piehip_ctx *h, u32 b0, u32 nb, u64 *results)
     } mask_div_scope{h};
     h->mask_div = nq;
     h->key_group = (nq > 1 && h->d_evkq && h->evkq_n == nq) ? nq : 1;  // per-query EvalMult keys: row r of a group is query r % nq
+    // Operand X of the first ciphertext product (the accumulators of inner hash function 0) is needed twice: in COEFFICIENT
+    // form by the base extension, and in EVALUATION form, lane-ordered, as the Q limbs of the QP operand (xq_reuse).  Until r04
+    // the inverse transform wrote that second copy; now stage A writes X there in the first place and the transform reads it
+    // from there (out of place, lane order in: its fast path) -- 44 MB less per step at the headline shape: the inverse launches
+    // 161 -> 150 us per step of three queries, stage A + 2.5 (its X rows leave in 64-byte runs) and the base extension + 2.5.
+    // Query batches only: one query's transform launches are single partial rounds that gain 1 us, and its stage A kernel, which
+    // runs at the HBM rate, loses 2.5 (profiles/r04/stage_a_writes_x_lane_ordered.txt).
+    const bool x_direct = K > 1 && nq > 1 && xq_reuse(h) && h->small_moduli && ntt16_applies(h->plan, h->fold_on);
     if (h->profiling) {  // an empty bracket: what the event pair itself costs on this stream (reported beside the kernels' times)
         ProfScope ps(h, PIEHIP_K_EVENT_PAIR, 0.0);
     }
@@ -1182,10 +1190,13 @@ static void enqueue_run_bins(piehip_ctx *h, u32 b0, u32 nb, u64 *results)
         qs.idx[0] = h->d_idx, qs.minus[0] = h->d_minus;
         for (u32 q = 1; q < nq; q++) qs.idx[q] = h->bq_idx[q], qs.minus[q] = h->bq_minus[q];
         const u64 *db = h->d_db + (size_t)b0 * E * LN;
+        StageAXOut xo;
+        if (x_direct) xo.out = w.eqp, xo.M = M, xo.logns = h->hp.logN - (h->fold_on ? 1 : 0);
         if (nq > 1) {
-            launch_stage_a_batch(h->d_dc, N, L, K, layers, E, qs, nq, db, acc, h->stream, h->small_moduli, b);
+            launch_stage_a_batch(h->d_dc, N, L, K, layers, E, qs, nq, db, acc, h->stream, h->small_moduli, b, 0, 0, x_direct ? &xo : nullptr);
         } else {
-            launch_stage_a(h->d_dc, N, L, K, nb, E, h->d_idx, h->d_minus, db, acc, h->stream, h->small_moduli, b);
+            launch_stage_a(h->d_dc, N, L, K, nb, E, h->d_idx, h->d_minus, db, acc, h->stream, h->small_moduli, b, 0, 0, 1, 0,
+                           x_direct ? &xo : nullptr);
         }
     }
     if (K == 1) {
@@ -1203,7 +1214,9 @@ static void enqueue_run_bins(piehip_ctx *h, u32 b0, u32 nb, u64 *results)
     ex.copy_K = K;
     ex.copy_L = L;
     ex.copy_M = M;
+    ex.x_lane_in = x_direct;
     ntt(h, acc, nb * K * 2 * L, 0, L, true, false, true, xq ? &ex : nullptr);
+    ex.x_lane_in = false;
     // product chain over the inner hash functions (BatchedFHEHIPPIE.cpp:117-124); the mask multiply
     // (:126) is fused into the last key switch
     const u64 *x = acc;
