@@ -97,8 +97,8 @@ void ntt(piehip_ctx *h, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_count, bool
 }
 // The X operand of a ciphertext multiplication is available in EVALUATION format before its inverse transform; when
 // the register-blocked kernel runs that transform it also drops a lane-ordered copy into the Q limbs of the QP operand
-// (for the first product of a query batch stage A has written X there already: enqueue_run_bins, x_direct)
-// array, and the forward transform over QP skips those limbs (8 of 36 per bin layer at L = 4).
+// array, and the forward transform over QP skips those limbs (8 of 36 per bin layer at L = 4).  (For the first product of a
+// query batch stage A has written X there already: enqueue_run_bins, x_direct.)
 bool xq_reuse(const piehip_ctx *h) { return h->sigma_on && ntt_supports_extra(h->plan, h->fold_on); }
 
 // BV key switch of the COEFFICIENT-format polynomials at w.d2c with `key`, added to the EVALUATION
