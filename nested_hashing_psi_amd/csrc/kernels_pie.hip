@@ -131,6 +131,24 @@ __device__ __forceinline__ u32 lane_home(u32 n, u32 logns)
     return (n & ~(ns - 1)) + 2 * ((ns >> 4) * ((e >> 1) & 7) + (e >> 4)) + (e & 1);
 }
 
+// a + b mod q for canonical a, b and q < 2^62, without the compare / select pair hipcc makes of addmod(): v_cndmask_b32 on VCC
+// issues at a sixth of the rate of the other vector instructions here (profiles/r03/microbench_operands.txt: 23.7 cycles per
+// wave against 4.2), and the epilogue of stage A has 24 of these sums per thread
+__device__ __forceinline__ u64 addmod_nb(u64 a, u64 b, u64 q)
+{
+    // (as an instruction block: written in C the compiler turns the mask back into a compare and a select)
+    const u64 s = a + b;
+    u32 lo, hi;
+    asm("v_lshl_add_u64 v[60:61], %[x], 0, %[nm]\n\t"  // s - q: negative iff s < q
+        "v_ashrrev_i32 v62, 31, v61\n\t"
+        "v_bfi_b32 %[lo], v62, %[xl], v60\n\t"
+        "v_bfi_b32 %[hi], v62, %[xh], v61"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi)
+        : [x] "v"(s), [xl] "v"((u32)s), [xh] "v"((u32)(s >> 32)), [nm] "s"(0 - q)
+        : "v62", "v60", "v61");
+    return ((u64)hi << 32) | lo;
+}
+
 static const int SA_DEPTH = 4;
 template <bool W124>
 __device__ __forceinline__ u64 colacc_reduce(const ColAcc &a, const Mod &m, u64 nq);  // (instruction block, defined below)
@@ -184,7 +202,8 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
             for (int t = 0; t < BPT; t++)
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    const u64 r = reduce124(colacc_value(a[t][c]), m);
+                    const u64 r = reduce124(colacc_value(a[t][c]), m);  // (the epilogue's instruction block here would cost this kernel, at seven
+                                                                       // layers per thread, its third wave per SIMD: 176 registers)
                     a[t][c] = ColAcc{r & 0x3FFFFFFFull, r >> 30, 0};
                 }
         }
@@ -194,18 +213,19 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__res
         for (int d = 0; d < SA_DEPTH; d++)
             if (j + d < E) term(j + d, qiv[d], qdv[d]);
     }
+    const bool xdir = h == 0 && xo.out != nullptr;
+    const u32 noff = n + ((xdir ? ~0u : 0u) & (lane_home(n, xo.logns) - n));
 #pragma unroll
     for (int t = 0; t < BPT; t++) {
         const size_t row = (size_t)(beta0 + t) * nq + q;
-        u64 *po = acc + ((row * K + h) * 2) * LN + (size_t)l * N + n;
-        size_t cstride = LN;
-        if (h == 0 && xo.out) {  // operand X of the first product: straight to the QP operand array, lane-ordered (StageAXOut)
-            po = xo.out + ((row * 4) * xo.M + l) * N + lane_home(n, xo.logns);
-            cstride = (size_t)xo.M * N;
-        }
+        // operand X of the first product goes straight to the QP operand array, lane-ordered (StageAXOut).  Uniform choices of
+        // base and stride, and the lane offset blended with a mask: no per-lane selects (v_cndmask on VCC: see addmod_nb)
+        u64 *const base = xdir ? xo.out + ((row * 4) * xo.M + l) * N : acc + ((row * K + h) * 2) * LN + (size_t)l * N;
+        const size_t cstride = xdir ? (size_t)xo.M * N : LN;
+        u64 *const po = base + noff;
 #pragma unroll
         for (int c = 0; c < 2; c++)
-            po[(size_t)c * cstride] = addmod(colacc_reduce<true>(a[t][c], m, 0 - m.q), minus[(size_t)c * LN + (size_t)l * N + n], m.q);
+            po[(size_t)c * cstride] = addmod_nb(colacc_reduce<true>(a[t][c], m, 0 - m.q), minus[(size_t)c * LN + (size_t)l * N + n], m.q);
     }
 }
 
@@ -273,7 +293,7 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_batch_kernel(const DevConsts 
                 for (int t = 0; t < BPT; t++)
 #pragma unroll
                     for (int c = 0; c < 2; c++) {
-                        const u64 r = reduce124(colacc_value(a[q][t][c]), m);
+                        const u64 r = colacc_reduce<true>(a[q][t][c], m, 0 - m.q);  // (the instruction block of the epilogue: no compare / select pairs)
                         a[q][t][c] = ColAcc{r & 0x3FFFFFFFull, r >> 30, 0};
                     }
         }
@@ -283,6 +303,8 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_batch_kernel(const DevConsts 
         for (int d = 0; d < DEPTH; d++)
             if (j + d < E) term(j + d, qiv[d], qdv[d]);
     }
+    const bool xdir = h == 0 && xo.out != nullptr;
+    const u32 noff = n + ((xdir ? ~0u : 0u) & (lane_home(n, xo.logns) - n));
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         u64 mi[2];
@@ -291,14 +313,13 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_batch_kernel(const DevConsts 
 #pragma unroll
         for (int t = 0; t < BPT; t++) {
             const size_t row = (size_t)(beta0 + t) * nq + q0 + q;
-            u64 *po = acc + ((row * K + h) * 2) * LN + (size_t)l * N + n;
-            size_t cstride = LN;
-            if (h == 0 && xo.out) {  // operand X of the first product: straight to the QP operand array, lane-ordered (StageAXOut)
-                po = xo.out + ((row * 4) * xo.M + l) * N + lane_home(n, xo.logns);
-                cstride = (size_t)xo.M * N;
-            }
+            // operand X of the first product goes straight to the QP operand array, lane-ordered (StageAXOut).  Uniform choices
+            // of base and stride, and the lane offset blended with a mask: no per-lane selects (v_cndmask on VCC: see addmod_nb)
+            u64 *const base = xdir ? xo.out + ((row * 4) * xo.M + l) * N : acc + ((row * K + h) * 2) * LN + (size_t)l * N;
+            const size_t cstride = xdir ? (size_t)xo.M * N : LN;
+            u64 *const po = base + noff;
 #pragma unroll
-            for (int c = 0; c < 2; c++) po[(size_t)c * cstride] = addmod(colacc_reduce<true>(a[q][t][c], m, 0 - m.q), mi[c], m.q);
+            for (int c = 0; c < 2; c++) po[(size_t)c * cstride] = addmod_nb(colacc_reduce<true>(a[q][t][c], m, 0 - m.q), mi[c], m.q);
         }
     }
 }
