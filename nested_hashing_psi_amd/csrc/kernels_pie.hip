@@ -152,6 +152,7 @@ __device__ __forceinline__ u64 addmod_nb(u64 a, u64 b, u64 q)
 static const int SA_DEPTH = 4;
 template <bool W124>
 __device__ __forceinline__ u64 colacc_reduce(const ColAcc &a, const Mod &m, u64 nq);  // (instruction block, defined below)
+__device__ __forceinline__ u64 colacc_reduce123_lazy(const ColAcc &a, const Mod &m, u64 nq);
 template <int BPT>
 __global__ void __launch_bounds__(TPB) stage_a_mad_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, u32 K, u32 b, u32 E,
                                                           const u64 *__restrict__ idx, const u64 *__restrict__ minus,
@@ -628,6 +629,45 @@ __device__ __forceinline__ u64 mulhi_sb(u64 a, u64 b)
 // remainder z + qhat (2^64 - q) on one v_mad_u64_u32 chain, sign-mask subtractions.  32 instructions (35 with W124) where the
 // compiler's colacc_value + reduce123 take ~65 (128-bit additions through v_cmp / v_cndmask carries, an 11-instruction mulhi).
 // W124: z < 2^124 (eight products), otherwise z < 2^123 (seven).
+// a three-column accumulator below 2^123 to v[66:67] in [0, 4q) (v60-v71, vcc, s[96:97] as scratch): the body of colacc_reduce<false>
+#define PIE_COLACC123_TO_4Q \
+    "v_lshrrev_b64 v[60:61], 30, %[c0]\n\t" \
+    "v_lshl_add_u64 v[60:61], v[60:61], 0, %[c1]\n\t" \
+    "v_lshrrev_b64 v[62:63], 30, v[60:61]\n\t" \
+    "v_lshl_add_u64 v[62:63], v[62:63], 0, %[c2]\n\t" \
+    "v_lshlrev_b64 v[64:65], 1, v[62:63]\n\t" \
+    "v_bfe_u32 v68, v60, 29, 1\n\t" \
+    "v_and_b32 v66, 0x3fffffff, %[c0l]\n\t" \
+    "v_bfe_u32 v67, v60, 2, 28\n\t" \
+    "v_or_b32 v64, v64, v68\n\t" \
+    "v_lshl_or_b32 v66, v60, 30, v66\n\t" \
+    "v_lshl_or_b32 v67, v62, 28, v67\n\t" \
+    "v_mul_hi_u32 v68, v64, %[mul]\n\t" \
+    "v_mov_b32 v69, 0\n\t" \
+    "v_mad_u64_u32 v[68:69], vcc, v64, %[muh], v[68:69]\n\t" \
+    "v_mad_u64_u32 v[68:69], vcc, v65, %[mul], v[68:69]\n\t" \
+    "v_mad_u64_u32 v[70:71], s[96:97], v65, %[muh], 0\n\t" \
+    "v_lshrrev_b64 v[68:69], 32, v[68:69]\n\t" \
+    "v_addc_co_u32 v69, vcc, 0, v69, vcc\n\t" \
+    "v_lshl_add_u64 v[68:69], v[70:71], 0, v[68:69]\n\t" \
+    "v_mad_u64_u32 v[70:71], vcc, v68, %[nqh], 0\n\t" \
+    "v_mad_u64_u32 v[70:71], vcc, v69, %[nql], v[70:71]\n\t" \
+    "v_add_u32 v67, v67, v70\n\t" \
+    "v_mad_u64_u32 v[66:67], vcc, v68, %[nql], v[66:67]\n\t"
+// ... left there: [0, 4q).  For values that go on into a folded forward transform (fold_store adds a [0, 4q) product to them and the
+// transform takes anything below 8q) or into a Shoup product (any operand below 2^63): eight instructions less than the canonical form
+__device__ __forceinline__ u64 colacc_reduce123_lazy(const ColAcc &a, const Mod &m, u64 nq)
+{
+    const u64 mu = (m.r1 << 59) | (m.r0 >> 5);   // floor(2^123 / q)
+    u64 r;
+    asm(PIE_COLACC123_TO_4Q
+        "v_lshl_add_u64 %[r], v[66:67], 0, 0"
+        : [r] "=v"(r)
+        : [c0] "v"(a.c0), [c1] "v"(a.c1), [c2] "v"(a.c2), [c0l] "v"((u32)a.c0), [mul] "s"((u32)mu), [muh] "s"((u32)(mu >> 32)),
+          [nql] "s"((u32)nq), [nqh] "s"((u32)(nq >> 32))
+        : PIE_ASM_CLOB, "s96", "s97");
+    return r;
+}
 template <bool W124>
 __device__ __forceinline__ u64 colacc_reduce(const ColAcc &a, const Mod &m, u64 nq)
 {
@@ -635,29 +675,7 @@ __device__ __forceinline__ u64 colacc_reduce(const ColAcc &a, const Mod &m, u64 
     const u64 n2q = 2 * nq, n4q = 4 * nq;
     u64 r;
     if (!W124) {
-        asm("v_lshrrev_b64 v[60:61], 30, %[c0]\n\t"
-            "v_lshl_add_u64 v[60:61], v[60:61], 0, %[c1]\n\t"
-            "v_lshrrev_b64 v[62:63], 30, v[60:61]\n\t"
-            "v_lshl_add_u64 v[62:63], v[62:63], 0, %[c2]\n\t"
-            "v_lshlrev_b64 v[64:65], 1, v[62:63]\n\t"
-            "v_bfe_u32 v68, v60, 29, 1\n\t"
-            "v_and_b32 v66, 0x3fffffff, %[c0l]\n\t"
-            "v_bfe_u32 v67, v60, 2, 28\n\t"
-            "v_or_b32 v64, v64, v68\n\t"
-            "v_lshl_or_b32 v66, v60, 30, v66\n\t"
-            "v_lshl_or_b32 v67, v62, 28, v67\n\t"
-            "v_mul_hi_u32 v68, v64, %[mul]\n\t"
-            "v_mov_b32 v69, 0\n\t"
-            "v_mad_u64_u32 v[68:69], vcc, v64, %[muh], v[68:69]\n\t"
-            "v_mad_u64_u32 v[68:69], vcc, v65, %[mul], v[68:69]\n\t"
-            "v_mad_u64_u32 v[70:71], s[96:97], v65, %[muh], 0\n\t"
-            "v_lshrrev_b64 v[68:69], 32, v[68:69]\n\t"
-            "v_addc_co_u32 v69, vcc, 0, v69, vcc\n\t"
-            "v_lshl_add_u64 v[68:69], v[70:71], 0, v[68:69]\n\t"
-            "v_mad_u64_u32 v[70:71], vcc, v68, %[nqh], 0\n\t"
-            "v_mad_u64_u32 v[70:71], vcc, v69, %[nql], v[70:71]\n\t"
-            "v_add_u32 v67, v67, v70\n\t"
-            "v_mad_u64_u32 v[66:67], vcc, v68, %[nql], v[66:67]\n\t"
+        asm(PIE_COLACC123_TO_4Q
             "v_lshl_add_u64 v[60:61], v[66:67], 0, %[n2q]\n\t"
             "v_ashrrev_i32 v62, 31, v61\n\t"
             "v_bfi_b32 v66, v62, v66, v60\n\t"
@@ -762,7 +780,8 @@ __device__ __forceinline__ U128 dot128(const u64 *y, const u64 (&c)[NS])
 
 // centred CRT lift of y_i-weighted residues from a source basis into target modulus `tm`:
 //   sum_i y_i * hat[i] - v * prodmod
-template <u32 NS, bool MAD>
+// LZ (MAD only): the result stays in [0, 4q) (colacc_reduce123_lazy)
+template <u32 NS, bool MAD, bool LZ = false>
 __device__ __forceinline__ u64 crt_out(const u64 *y, const u64 (&hat)[NS], u64 v, u64 prodmod, const Mod &tm, u64 negq, u64 neg2q)
 {
     if (MAD && NS <= 7) {
@@ -772,7 +791,7 @@ __device__ __forceinline__ u64 crt_out(const u64 *y, const u64 (&hat)[NS], u64 v
 #pragma unroll
         for (u32 i = 0; i < NS; i++) colacc_mac(a, split30(y[i]), split30(hat[i]));
         colacc_mac_small(a, (u32)v, tm.q - prodmod);  // - v * prodmod (mod tm)
-        return colacc_reduce<false>(a, tm, negq);
+        return LZ ? colacc_reduce123_lazy(a, tm, negq) : colacc_reduce<false>(a, tm, negq);
     }
     U128 acc = dot128<NS, MAD>(y, hat);
     mac128(acc, v, tm.q - prodmod);  // - v * prodmod (mod tm); v <= ns: one Barrett reduction for the whole sum
@@ -794,7 +813,7 @@ __device__ __forceinline__ void fold_load(const DevConsts *dc, u32 a, u64 u, u64
     x0 = shoup63(u + v, c->fold_ia[a], c->fold_ia_sh[a], nq);            // (folding implies q < 2^60)
     x1 = shoup63(u + (4 * q - v), c->fold_ib[a], c->fold_ib_sh[a], nq);
 }
-// u canonical; results in (0, 5q)
+// u in [0, 4q) (canonical, or left unreduced by the base conversions: LZ); results in (0, 8q)
 __device__ __forceinline__ void fold_store(const DevConsts *dc, u32 a, u64 u, u64 v, u64 &y0, u64 &y1)
 {
     const DcC c = dc_iter(dc);
@@ -810,7 +829,7 @@ __device__ __forceinline__ void fold_store(const DevConsts *dc, u32 a, u64 u, u6
 // x[L] (mod Q) -> out[M]: Q limbs copied, P limbs = centred CRT lift
 // YIN: x[] already holds the CRT digits y_i = [x_i (Q/q_i)^-1]_{q_i} (folded load with the merged constants); the Q
 // limbs of the output are then not produced
-template <u32 L, bool MAD, bool YIN, int NP>
+template <u32 L, bool MAD, bool YIN, int NP, bool LZ = false>
 __device__ __forceinline__ void expand_core(const DevConsts *dc, const u64 (&x)[NP][L], u64 (&out)[NP][2 * L + 1])
 {
     constexpr u32 Lp = L + 1;
@@ -841,12 +860,12 @@ __device__ __forceinline__ void expand_core(const DevConsts *dc, const u64 (&x)[
         for (u32 i = 0; i < L; i++) hat[i] = c->qhat_modp[i][j];
         const u64 prodmod = c->Q_modp[j], nq = neg_u(pj.q), n2q = neg_u(2 * pj.q);
 #pragma unroll
-        for (int p = 0; p < NP; p++) out[p][L + j] = crt_out<L, MAD>(y[p], hat, (fsum[p] + FIX_HALF) >> 60, prodmod, pj, nq, n2q);
+        for (int p = 0; p < NP; p++) out[p][L + j] = crt_out<L, MAD, LZ>(y[p], hat, (fsum[p] + FIX_HALF) >> 60, prodmod, pj, nq, n2q);
     }
 }
 
 // x[L] (mod Q) -> out[M]: P limbs = round(P x / Q), Q limbs = centred CRT lift of that
-template <u32 L, bool MAD, bool YIN, int NP>
+template <u32 L, bool MAD, bool YIN, int NP, bool LZ = false>
 __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 (&x)[NP][L], u64 (&out)[NP][2 * L + 1])
 {
     constexpr u32 Lp = L + 1;
@@ -894,7 +913,7 @@ __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 (&x
                 ColAcc a = {itot[p].lo, 0, 0};
 #pragma unroll
                 for (u32 i = 0; i < L; i++) colacc_mac(a, split30(y[p][i]), split30(col[i]));
-                r = colacc_reduce<false>(a, pj, nq);
+                r = LZ ? colacc_reduce123_lazy(a, pj, nq) : colacc_reduce<false>(a, pj, nq);  // (LZ: feeds a Shoup product and fold_store)
             } else {
                 U128 acc = dot128<L, MAD>(y[p], col);
                 add128(acc, itot[p]);
@@ -915,7 +934,7 @@ __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 (&x
         for (u32 j = 0; j < Lp; j++) hat[j] = c->phat_modq[j][i];
         const u64 prodmod = c->P_modq[i], nq = neg_u(mi.q), n2q = neg_u(2 * mi.q);
 #pragma unroll
-        for (int p = 0; p < NP; p++) out[p][i] = crt_out<Lp, MAD>(yp[p], hat, (fs2[p] + FIX_HALF) >> 60, prodmod, mi, nq, n2q);
+        for (int p = 0; p < NP; p++) out[p][i] = crt_out<Lp, MAD, LZ>(yp[p], hat, (fs2[p] + FIX_HALF) >> 60, prodmod, mi, nq, n2q);
     }
 }
 
@@ -949,10 +968,12 @@ __device__ __forceinline__ void expand_body(const DevConsts *__restrict__ dc, u3
             x[0][i] = pin[(size_t)i * N];
         }
     }
+    // folded output: every result passes through fold_store into a transform that takes [0, 8q) -- [0, 4q) will do (LZ)
+    constexpr bool LZ = FOLD && MAD;
     if (SCALE)
-        scale_pq_core<L, MAD, YIN, NP>(dc, x, y);
+        scale_pq_core<L, MAD, YIN, NP, LZ>(dc, x, y);
     else
-        expand_core<L, MAD, YIN, NP>(dc, x, y);
+        expand_core<L, MAD, YIN, NP, LZ>(dc, x, y);
 #pragma unroll
     for (u32 a = 0; a < M; a++) {
         if (!SCALE && a < L && SKIPQ) continue;  // (NttExtra)
@@ -1097,8 +1118,10 @@ void launch_tensor(const DevConsts *dc, u32 N, u32 M, const u64 *e, u64 *d, u32 
 // Scale-and-round by t/P from QP into Q (row A6)
 // ---------------------------------------------------------------------------------------------
 // d[M] (mod QP) -> out[L]: round(t d / P) mod Q
+// lz (MAD, L <= 5): the results stay in [0, 4q) (colacc_reduce123_lazy): for components that go through fold_store into a
+// transform of the 16-coefficient kernel
 template <u32 L, bool MAD, int NP>
-__device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 (&d)[NP][2 * L + 1], u64 (&out)[NP][L])
+__device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 (&d)[NP][2 * L + 1], u64 (&out)[NP][L], bool lz = false)
 {
     constexpr u32 Lp = L + 1;
     u64 yp[NP][Lp];
@@ -1139,7 +1162,7 @@ __device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 
 #pragma unroll
                 for (u32 j = 0; j < Lp; j++) colacc_mac(a, split30(yp[p][j]), split30(col[j]));
                 colacc_mac(a, split30(d[p][k]), split30(tp));
-                out[p][k] = colacc_reduce<(L > 5)>(a, qk, nq);
+                out[p][k] = (L <= 5 && lz) ? colacc_reduce123_lazy(a, qk, nq) : colacc_reduce<(L > 5)>(a, qk, nq);
             } else {
                 U128 acc = dot128<Lp, MAD>(yp[p], col);
                 mac128(acc, d[p][k], tp);
@@ -1173,7 +1196,9 @@ __global__ void __launch_bounds__(TPB) scale_round_kernel(const DevConsts *__res
         else
             x[0][a] = pin[(size_t)a * N];
     }
-    scale_round_core<L, MAD, NP>(dc, x, y);
+    // d0, d1 of the key-switch path go on through fold_store into the forward transform ([0, 8q) in): [0, 4q) will do.  d2 feeds the
+    // digit lift (canonical), and with fold_comp2 the three components leave the library's lane-ordered world
+    scale_round_core<L, MAD, NP>(dc, x, y, FOLD && MAD && comp < 2 && !fold_comp2);
 #pragma unroll
     for (u32 k = 0; k < L; k++) {
         PIE_ITER_FENCE();
