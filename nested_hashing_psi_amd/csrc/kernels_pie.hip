@@ -1120,7 +1120,9 @@ void launch_tensor(const DevConsts *dc, u32 N, u32 M, const u64 *e, u64 *d, u32 
 // d[M] (mod QP) -> out[L]: round(t d / P) mod Q
 // lz (MAD, L <= 5): the results stay in [0, 4q) (colacc_reduce123_lazy): for components that go through fold_store into a
 // transform of the 16-coefficient kernel
-template <u32 L, bool MAD, int NP>
+// PRE: the inputs come from a folded load with the merged constants (DevConsts::fold_iap / fold_iat): the P limbs already hold
+// yp_j = [d_j (QP/p_j)^-1]_{p_j}, the Q limbs [d_k t P^-1]_{q_k} -- the products this routine would form first
+template <u32 L, bool MAD, int NP, bool PRE = false>
 __device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 (&d)[NP][2 * L + 1], u64 (&out)[NP][L], bool lz = false)
 {
     constexpr u32 Lp = L + 1;
@@ -1137,7 +1139,7 @@ __device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 
         const u64 w = c->qp_hat_inv[L + j], wsh = c->qp_hat_inv_sh[L + j], tw = c->tQ_modp[j], twsh = c->tQ_modp_sh[j], nq = neg_u(pj.q);
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            yp[p][j] = mshoup<MAD>(d[p][L + j], w, wsh, pj.q, nq);
+            yp[p][j] = PRE ? d[p][L + j] : mshoup<MAD>(d[p][L + j], w, wsh, pj.q, nq);
             u64 fl, z;
             mdivmod<MAD>(yp[p][j], tw, twsh, pj.q, nq, fl, z);
             add128(itot[p], U128{fl, 0});
@@ -1161,11 +1163,17 @@ __device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 
                 ColAcc a = {itot[p].lo, 0, 0};
 #pragma unroll
                 for (u32 j = 0; j < Lp; j++) colacc_mac(a, split30(yp[p][j]), split30(col[j]));
-                colacc_mac(a, split30(d[p][k]), split30(tp));
+                if (PRE)
+                    a.c0 += d[p][k];  // (canonical, < 2^60: column 0 holds L + 2 products' low parts and the integer parts besides)
+                else
+                    colacc_mac(a, split30(d[p][k]), split30(tp));
                 out[p][k] = (L <= 5 && lz) ? colacc_reduce123_lazy(a, qk, nq) : colacc_reduce<(L > 5)>(a, qk, nq);
             } else {
                 U128 acc = dot128<Lp, MAD>(yp[p], col);
-                mac128(acc, d[p][k], tp);
+                if (PRE)
+                    add128(acc, U128{d[p][k], 0});
+                else
+                    mac128(acc, d[p][k], tp);
                 add128(acc, itot[p]);
                 out[p][k] = reduce128(acc, qk);
             }
@@ -1191,14 +1199,23 @@ __global__ void __launch_bounds__(TPB) scale_round_kernel(const DevConsts *__res
     u64 x[NP][M], y[NP][L];
 #pragma unroll
     for (u32 a = 0; a < M; a++) {
-        if (FOLD)
-            fold_load(dc, a, pin[(size_t)a * N], pin[(size_t)a * N + H], x[0][a], x[NP - 1][a]);
-        else
+        if (FOLD) {
+            // the folded load and the first product of scale-and-round in one Shoup multiplication (merged constants)
+            PIE_ITER_FENCE();
+            const DcC c = dc_iter(dc);
+            const u32 ak = a < L ? a : 0, aj = a < L ? 0 : a - L;
+            const u64 q = c->mod[a].q, nq = neg_u(q), u = pin[(size_t)a * N], v = pin[(size_t)a * N + H];
+            const u64 wa = a < L ? c->fold_iat[ak] : c->fold_iap[aj], was = a < L ? c->fold_iat_sh[ak] : c->fold_iap_sh[aj];
+            const u64 wb = a < L ? c->fold_ibt[ak] : c->fold_ibp[aj], wbs = a < L ? c->fold_ibt_sh[ak] : c->fold_ibp_sh[aj];
+            x[0][a] = shoup63(u + v, wa, was, nq);                // u, v in [0, 4q)
+            x[NP - 1][a] = shoup63(u + (4 * q - v), wb, wbs, nq);
+        } else {
             x[0][a] = pin[(size_t)a * N];
+        }
     }
     // d0, d1 of the key-switch path go on through fold_store into the forward transform ([0, 8q) in): [0, 4q) will do.  d2 feeds the
     // digit lift (canonical), and with fold_comp2 the three components leave the library's lane-ordered world
-    scale_round_core<L, MAD, NP>(dc, x, y, FOLD && MAD && comp < 2 && !fold_comp2);
+    scale_round_core<L, MAD, NP, FOLD>(dc, x, y, FOLD && MAD && comp < 2 && !fold_comp2);
 #pragma unroll
     for (u32 k = 0; k < L; k++) {
         PIE_ITER_FENCE();

@@ -236,6 +236,20 @@ std::string HostParams::init(u32 N_, u32 L_, u64 t_, const u64 *q, const u64 *p)
         dc.qp_hat_inv[a] = invmod(prod_mod(moduli.data(), M, (int)a, moduli[a]), moduli[a]);
         dc.qp_hat_inv_sh[a] = shoup(dc.qp_hat_inv[a], moduli[a]);
     }
+    for (u32 j = 0; j < Lp; j++) {
+        const u64 pj = P[j];
+        dc.fold_iap[j] = mm(dc.fold_ia[L + j], dc.qp_hat_inv[L + j], pj);
+        dc.fold_iap_sh[j] = shoup(dc.fold_iap[j], pj);
+        dc.fold_ibp[j] = mm(dc.fold_ib[L + j], dc.qp_hat_inv[L + j], pj);
+        dc.fold_ibp_sh[j] = shoup(dc.fold_ibp[j], pj);
+    }
+    for (u32 k = 0; k < L; k++) {
+        const u64 qk = Q[k];
+        dc.fold_iat[k] = mm(dc.fold_ia[k], dc.tPinv_modq[k], qk);
+        dc.fold_iat_sh[k] = shoup(dc.fold_iat[k], qk);
+        dc.fold_ibt[k] = mm(dc.fold_ib[k], dc.tPinv_modq[k], qk);
+        dc.fold_ibt_sh[k] = shoup(dc.fold_ibt[k], qk);
+    }
     return "";
 }
 

@@ -46,6 +46,10 @@ struct DevConsts {
     u64 fold_ib[MAX_M + 1], fold_ib_sh[MAX_M + 1];  // inverse: psi^{-N/2} N^-1 (difference branch)
     // the same two constants times (Q/q_i)^-1: the CRT digit y_i of a base conversion straight from the folded load
     u64 fold_iaq[8], fold_iaq_sh[8], fold_ibq[8], fold_ibq_sh[8];
+    // ... times (QP/p_j)^-1 for the P limbs and times t P^-1 for the Q limbs: what scale-and-round multiplies its folded inputs by
+    // first anyway (scale_round_core: yp and the own-limb term)
+    u64 fold_iap[8], fold_iap_sh[8], fold_ibp[8], fold_ibp_sh[8];
+    u64 fold_iat[8], fold_iat_sh[8], fold_ibt[8], fold_ibt_sh[8];
     // client harness (encryption / decryption): t^-1 mod q_i, [Q]_t, Shoup companion of t mod q_i
     u64 t_inv_modq[8];
     u64 t_modq_sh[8];
