@@ -697,6 +697,9 @@ def test_caller_supplied_moduli(ob, pie, N, L, t, below, what):
     (8192, 3, T32, 2, 4, 7, (6,)),                 # 3 + 3 queries, b = 7: 4 + 3 / 2 + 2 + 2 + 1 layers per thread
     (16384, 4, T32, 2, 14, 1, (3,)),               # one bin layer: a rank's share of b = 14 over eight GPUs
     (16384, 4, T32, 2, 14, 2, (3,)),               # ... and two
+    (8192, 3, T32, 3, 5, 4, (3,)),                 # K = 3 on a ring of the 16-coefficient transform (one slice per limb): X of the first product
+                                                   # comes lane-ordered from stage A, X of the second is the first product itself
+    (16384, 4, T32, 3, 3, 3, (2,)),                # ... with folded slices
 ])
 def test_query_batches(ob, pie, N, L, t, K, E, b, nqs):
     """piehip_set_query_batch: run() over nq queries at once.  Every query's ciphertexts equal the oracle's for that query alone
