@@ -16,6 +16,7 @@ parity with OpenFHE itself is unpinned.
       + the same database with THREE different queries in one run() on one handle: bench.py's default timed region
       + the reference's alternative row for these set sizes, E=20 b=10 (Parameters1.txt:35)
   C5  N=32768, 6 primes,               |S|=2^24, |C|=2^12, k=2 e=13004 K=3 E=30 b=30   (Parameters1.txt:19 with -K 3)
+      + C2 and C5 with three queries per run() (what bench.py --config C2 / C5 time by default)
   KAT-0 at the reference test's own parameters: tests/TestBatchedFHEPIE.cpp:14-41,89-94 (N=16384, 33-bit t).
 C4 (C3's bin layers over several GPUs) is tests/test_sharding_gpu.py.
 """
@@ -150,6 +151,21 @@ def test_c5_full_size(ob, pie_mod):
     b = 30
     budget = run_case(ob, pie_mod, 32768, 6, T32, 1 << 24, 1 << 12, 2, 13004, 3, 30, b, 2024, range(b))   # all 30 bin layers
     assert budget > 0
+
+
+def test_c5_batch_of_three(ob, pie_mod):
+    """What `bench.py --config C5` times by default: three queries per run() at C5's real shape (Parameters1.txt:19 with -K 3).  The
+    batched stage A with E = 30 (two accumulator sweeps) writes operand X of the first product lane-ordered into the QP array,
+    ntt16_kernel_t<14, ...> reads it there, the second product's X is the first product; L = 6, 30 bin layers over two queues.  Every
+    query's 30 result ciphertexts equal the oracle's run() of that query alone."""
+    b = 30
+    budget = run_case(ob, pie_mod, 32768, 6, T32, 1 << 24, 1 << 12, 2, 13004, 3, 30, b, 2025, range(b), nq=3)
+    assert budget > 0
+
+
+def test_c2_batch_of_three(ob, pie_mod):
+    """`bench.py --config C2`'s default timed region (Parameters1.txt:53): three queries per run() on the one-slice-per-limb ring"""
+    run_case(ob, pie_mod, 8192, 3, T32, 1 << 16, 1 << 10, 3, 443, 2, 12, 12, 8, range(12), nq=3)
 
 
 @pytest.mark.parametrize("N,L,t", [(4096, 2, T16), (16384, 4, T32)])

@@ -700,6 +700,9 @@ def test_caller_supplied_moduli(ob, pie, N, L, t, below, what):
     (8192, 3, T32, 3, 5, 4, (3,)),                 # K = 3 on a ring of the 16-coefficient transform (one slice per limb): X of the first product
                                                    # comes lane-ordered from stage A, X of the second is the first product itself
     (16384, 4, T32, 3, 3, 3, (2,)),                # ... with folded slices
+    (32768, 6, T32, 3, 4, 3, (3, 2)),              # the 2^14-slice geometry (C5's ring, L = 6, K = 3): stage A writes operand X lane-ordered into the QP array
+                                                   # and ntt16_kernel_t<14, ...> reads it there; the second product's X is the first product itself
+    (32768, 6, T32, 2, 17, 2, (3,)),               # ... E past the carry sweep of the batched stage A on that ring
 ])
 def test_query_batches(ob, pie, N, L, t, K, E, b, nqs):
     """piehip_set_query_batch: run() over nq queries at once.  Every query's ciphertexts equal the oracle's for that query alone
@@ -894,6 +897,7 @@ def test_staged_query_upload(ob, pie):
     (16384, 4, T32, 2, 3, 9, 2),       # the headline ring, two queues (5 + 4 layers): results leave per queue group
     (2048, 3, T32, 3, 5, 4, 4),        # K = 3: three rows per query, two chained products
     (16384, 4, T32, 2, 14, 3, 3),      # E = 14 as at C3, batch of three
+    (32768, 6, T32, 3, 3, 3, 3),       # C5's ring (2^14 slices, L = 6), K = 3, batch of three through the host-memory path
 ])
 def test_staged_query_batches(ob, pie, N, L, t, K, E, b, nq):
     """The host-memory path of a query batch -- what a server with nq clients connected calls (BatchedFHEPSIServer.cpp:94-108 per
