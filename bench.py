@@ -442,6 +442,20 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
     pi[...] = idx_h
     pm[...] = minus_h
     host_pinned = med(lambda: op.runHost(pi, pm, pr), iters)
+    # Every stream leg also reports how long its staging sequences waited (on the host) for their turn on the PCIe link
+    # (piehip_upload_turn_wait): a leg that runs far from the link bound names its wait -- the staging thread of slot B polls a
+    # page-locked word until slot A's query has left host memory, and that poll is the one place of this path where the host blocks.
+    turn_wait = {"run_host_async_stream": {}, "staged_batch_stream": {}}
+
+    def turn_waits(ops_):
+        return [o_.cc.upload_turn_wait() for o_ in ops_]
+
+    def turn_wait_delta(ops_, before, nqueries):
+        after = turn_waits(ops_)
+        tot = sum(a_[1] - b_[1] for a_, b_ in zip(after, before))
+        cnt = sum(a_[2] - b_[2] for a_, b_ in zip(after, before))
+        return {"ms_per_query": tot / nqueries, "waits": cnt, "ms_per_wait": (tot / cnt if cnt else 0.0)}
+
     # a stream of queries from host memory over the query slots (piehip_run_host_async / _wait, page-locked staging per slot):
     # slot B's 29 MiB cross PCIe while slot A evaluates, so a query costs its upload, not upload + run + download
     pipelined = {}
@@ -466,9 +480,11 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
 
             stream_queries()
             torch.cuda.synchronize(device)
+            w0 = turn_waits(allops)
             t0 = time.perf_counter()
             stream_queries()
             pipelined[nslots] = (time.perf_counter() - t0) / nq
+            turn_wait["run_host_async_stream"][str(nslots)] = turn_wait_delta(allops, w0, nq)
     # The same stream with BATCHES of queries (the default timed region's mode, reached through the host-memory boundary the
     # reference's server uses): every slot takes `batch` queries per run(), each query staged piece by piece from its own
     # page-locked arrays (piehip_stage_*_q: minus elements first, then the index matrices row by row across the batch), the
@@ -507,9 +523,11 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
 
             stream_batches()
             torch.cuda.synchronize(device)
+            w0 = turn_waits(allops)
             t0 = time.perf_counter()
             stream_batches()
             batched[nslots] = (time.perf_counter() - t0) / (nbatches * batch)
+            turn_wait["staged_batch_stream"][str(nslots)] = turn_wait_delta(allops, w0, nbatches * batch)
             for o in allops:
                 o.setQueryBatch(1)
     # leave the operators as the timed region expects them: inputs resident
@@ -528,7 +546,7 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
         best = min(batched, key=batched.get)
         out.update({"staged_batch_stream_ms_per_query": {str(n_): v_ * 1e3 for n_, v_ in batched.items()}, "staged_batch_queries_per_run": batch,
                     "staged_batch_slots": best, "value_staged_batch_stream": b / batched[best]})
-    return {**out, "unit": "ms", "iters": iters,
+    return {**out, "unit": "ms", "iters": iters, "upload_turn_wait_ms": turn_wait,
             "separate_calls_ms": sep * 1e3, "separate_calls_with_results_ms": sep_res * 1e3,
             "run_host_pageable_with_results_ms": host_pageable * 1e3, "run_host_pinned_with_results_ms": host_pinned * 1e3,
             "value_separate_calls": b / sep, "value_run_host_pinned_with_results": b / host_pinned,
@@ -551,6 +569,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end PSI wall-clock leg")
     ap.add_argument("--no-projection", action="store_true", help="skip the projected strong-scaling legs")
+    ap.add_argument("--transform-slots", type=int, default=None,
+                    help="cap on the persistent transform grids (workgroups); default: every slot on one GPU, 32 fewer (16 CUs left to RCCL) for N > 1")
     ap.add_argument("--no-ref-timer", action="store_true", help="skip the host-inputs (reference timer placement) leg")
     ap.add_argument("--timed-only", action="store_true",
                     help="only the timed region and the per-kernel passes: no further legs (for profiler runs, whose per-kernel "
@@ -685,6 +705,17 @@ def main():
                 o_.setIndexDevice(iq.data_ptr(), query=q_)
                 o_.setMinusCompareElementDevice(mq.data_ptr(), query=q_)
         torch.cuda.synchronize(device)
+    # N > 1: leave CUs to RCCL's kernels.  The transforms are persistent grids on every workgroup slot of the device (two per CU, with
+    # the CU's whole register file) for 60-100 us at a time; the broadcast of the next query and the gather of the previous results
+    # need CUs during exactly those launches.  Default: 16 CUs (32 slots) free on every rank; --transform-slots 0 fills the device.
+    tcap, tdev = cc.transform_slots()
+    if args.transform_slots is not None:
+        tcap = args.transform_slots
+    elif world > 1 and not args.rehearse_on_one_gpu:
+        tcap = max(2, tdev - 32)
+    for s_ in slots:
+        if s_[0] is not None:
+            s_[0].set_transform_slots(tcap)
     ct_words = 2 * L * N
     rg = None
     rgs = []
@@ -808,10 +839,9 @@ def main():
             out_.append(agree(time.perf_counter() - t0, dist.ReduceOp.MAX if dist else None) / args.steps * 1e3)
         return out_
 
-    # The timed region: the queries are resident in HBM when a step starts -- on every rank for N > 1, as on the one GPU of N = 1
-    # (the reference's timer starts after the query has been received, BatchedFHEPSIServer.cpp:94-99; a sharded server distributes
-    # it underneath that receive loop).  N > 1 then times the same steps once more WITH the per-query distribution from rank 0
-    # inside every step (`with_query_distribution` in the line).
+    # The timed region.  N = 1: the queries are resident in HBM when a step starts.  N > 1: they are resident in RANK 0's HBM (the
+    # rank that holds the client's socket, BatchedFHEPSIServer.cpp:94-99) and every step distributes its queries to all ranks -- the
+    # line's `value`; the steps are first timed with the queries already on every rank (`queries_resident_on_every_rank`).
     blocks = run_blocks()
     ms_per_step = median(blocks)
     dist_blocks = None
@@ -881,6 +911,14 @@ def main():
         for c_, o_, st_, i_, m_ in slots[:in_flight]:
             if o_ is not None:
                 o_.setQueryBatch(1)
+    resident_blocks = None
+    if dist_blocks:
+        # N > 1: the headline is the step WITH the per-query distribution from rank 0 -- what the shipped sharded servers do inside
+        # their online timer (host/ShardedBatchedFHEPSIServer.hpp evaluateStagedQuery: piehip_rccl_broadcast_query, run, gather);
+        # the steps with the queries already resident on every rank are reported beside it (`queries_resident_on_every_rank`).
+        # (r04 had the two the other way round: ADVICE r04.)
+        resident_blocks, blocks = blocks, dist_blocks
+        ms_per_step = median(blocks)
     if rank == 0:
         value = batch * b_total / (ms_per_step * 1e-3)
         cname = "C4 (C3's bin layers over %d GPUs)" % world if (world > 1 and scaling == "strong" and args.config == "C3") else args.config
@@ -897,10 +935,14 @@ def main():
                                       b_total, b_local, batch, "y" if batch == 1 else "ies", batch * b_total * K * E, batch * b_total * (K - 1),
                                       batch * b_total),
                        "result_ciphertexts_per_step": batch * b_total, "queries_per_step": batch, "parallelism": "bins%d" % world,
-                       "collective": ("%s: %s of results to rank 0 inside every step, one communicator per query slot and direction; queries "
-                                      "resident on every rank (timed again with %s of the queries from rank 0 (%s): with_query_distribution)"
-                                      % ("gloo (rehearsal)" if args.rehearse_on_one_gpu else "rccl", args.collective,
-                                         qdist_kind or "no distribution", args.query_source)) if use_dist else "none",
+                       "collective": ("%s: inside every step %s of its queries from rank 0 (%s memory) to every rank and %s of the results to "
+                                      "rank 0, one communicator per query slot and direction%s"
+                                      % ("gloo (rehearsal)" if args.rehearse_on_one_gpu else "rccl", qdist_kind or "NO distribution",
+                                         args.query_source, args.collective,
+                                         "; the same steps with the queries resident on every rank: queries_resident_on_every_rank" if dist_blocks else
+                                         " (queries resident on every rank)")) if use_dist else "none",
+                       "rccl_ranks": (dist.get_world_size() if dist else 1), "backend": (dist.get_backend() if dist else "none"),
+                       "transform_slots": {"cap": tcap, "device": tdev},
                        "query_distribution_s": qdist_times,
                        "queries_in_flight": in_flight},
             "mac_per_s": batch * b_total * K * E / (ms_per_step * 1e-3), "mul_per_s": batch * b_total * (K - 1) / (ms_per_step * 1e-3),
@@ -916,14 +958,15 @@ def main():
                              "note": "bytes of the reference's unfused schedule / measured time / 8 TB/s; not measured HBM traffic"},
             "roofline": roofline, "kernels": kernels,
         }
-        if dist_blocks:
-            dms = median(dist_blocks)
-            line["with_query_distribution"] = {
-                "ms_per_step": dms, "value": batch * b_total / (dms * 1e-3), "ms_per_step_min": min(dist_blocks), "ms_per_step_max": max(dist_blocks),
-                "kind": qdist_kind, "source": args.query_source,
-                "what": "the same steps with every step's %d quer%s (%.1f MiB) travelling from rank 0 to every rank inside the step "
-                        "(shard.QueryBroadcast on the slot's own communicator); `value` above has them resident on every rank"
-                        % (batch, "y" if batch == 1 else "ies", q_words * 8 / 2**20)}
+        if resident_blocks:
+            rms = median(resident_blocks)
+            line["query_distribution"] = {"kind": qdist_kind, "source": args.query_source, "MiB_per_step": q_words * 8 / 2**20}
+            line["queries_resident_on_every_rank"] = {
+                "ms_per_step": rms, "value": batch * b_total / (rms * 1e-3), "ms_per_step_min": min(resident_blocks),
+                "ms_per_step_max": max(resident_blocks),
+                "what": "the same steps WITHOUT the per-query distribution: every step's %d quer%s already resident in every rank's HBM "
+                        "when the step starts.  No shipped server works like that (the C++ sharded server broadcasts inside its online "
+                        "timer); `value` above has the distribution inside every step" % (batch, "y" if batch == 1 else "ies")}
         if world == 1 and op is not None and (in_flight > 1 or batch > 1) and not args.bins_per_rank and not args.timed_only:
             # the same steps with one query at a time (one slot, one query per run(), the library's default of two queues)
             cc.set_run_streams(args.streams)

@@ -183,6 +183,9 @@ int piehip_stage_index_row_q(piehip_handle h, uint32_t q, uint32_t row, const ui
 int piehip_stage_index_ct_q(piehip_handle h, uint32_t q, uint32_t row, uint32_t j, const uint64_t *ct);
 int piehip_stage_reset(piehip_handle h);
 int piehip_run_staged(piehip_handle h, uint64_t *results);
+/* how long this handle's staging sequences waited (on the host) for their turn on the device's link: the last one, all of them,
+ * and how many waited at all.  A wait that reaches 5 s returns PIEHIP_EHIP from the staging call instead of going on silently. */
+int piehip_upload_turn_wait(piehip_handle h, double *last_ms, double *total_ms, uint64_t *waits);
 /* Stream order.  run() works on the handle's own queues (piehip_set_run_streams); it waits for the handle's stream
  * where it must (new inputs; the result buffer), and the handle's stream waits for the run in the next call of any
  * other entry point -- piehip_join() does only that, piehip_sync() also blocks the host.  Work queued on the handle's
@@ -193,6 +196,12 @@ int piehip_sync(piehip_handle h);
  * one group's launches are filled by another group's; n = 1 serialises everything on the handle's stream (per-kernel
  * timing), 0 = the default (2).  The results are complete on the handle's stream either way. */
 int piehip_set_run_streams(piehip_handle h, uint32_t n);
+/* The transforms are persistent grids that fill every workgroup slot of the device (two per CU) for 60-100 us at a time, with the
+ * CU's whole register file.  A sharded server's RCCL kernels (broadcast of the next query, gather of the previous results) need
+ * CUs during exactly those launches: n > 0 caps the transforms' grids at n workgroups (n < 2 x CUs leaves (2 x CUs - n) / 2 CUs
+ * free; results are bit-identical for every n), 0 = the default, every slot.  Applies to this handle's later runs. */
+int piehip_set_transform_slots(piehip_handle h, uint32_t n);
+int piehip_get_transform_slots(piehip_handle h, uint32_t *n /* the cap, 0 = none */, uint32_t *device_slots /* 2 x CUs */);
 /* on != 0: run() / run_into() replay one captured hipGraph (all launches of both queue groups, forked from and joined back to
  * the handle's stream) instead of enqueueing ~26 launches; re-captured when the input arrays, the result buffer or the queue
  * count change.  Amortises the launch path when a handle evaluates few bin layers (one rank's share of a sharded server);
@@ -265,6 +274,20 @@ int piehip_gather_results(piehip_handle h, uint32_t b_total, int root, void *d_o
 /* the same, with the gathered list brought down to host memory on the root: *results (root only; NULL elsewhere) is a page-locked
  * array [b_total][nq][2][L][N] owned by the handle, complete after piehip_sync -- what sendResult (.cpp:143-152) reads */
 int piehip_gather_results_host(piehip_handle h, uint32_t b_total, int root, uint64_t **results);
+/* Nobody waits for the other ranks without a bound.  A collective completes when EVERY rank has queued its side; a rank that
+ * never does (it died; it returned an error from one of the calls above before anything was queued) would leave its peers'
+ * streams blocked for ever.  The reference ends the process on any error (BatchedFHEHIPPIE.cpp:15,20); a sharded server does the
+ * same for the whole group:
+ *   piehip_rccl_wait    piehip_sync with a time-out (milliseconds): polls the handle's stream and the communicator's asynchronous
+ *                       error state; when the time is up or RCCL reports a failed peer it aborts the communicator (ncclCommAbort
+ *                       releases the blocked stream) and returns PIEHIP_EHIP -- the handle has no communicator afterwards
+ *   piehip_rccl_abort   the same on purpose: a rank on its way out tears its side down, its peers' waits end at once
+ *   piehip_rccl_agree   *all_ok = (every rank passed ok != 0): one all-reduced word + piehip_rccl_wait; called at the end of a phase
+ *                       (database built, key loaded) so that a failure on one rank ends the session on all of them BEFORE anybody
+ *                       enters a collective the failed rank will not join.  Not part of the per-query path. */
+int piehip_rccl_wait(piehip_handle h, uint32_t timeout_ms);
+int piehip_rccl_abort(piehip_handle h);
+int piehip_rccl_agree(piehip_handle h, int ok, int *all_ok, uint32_t timeout_ms);
 
 /* ---- the OpenFHE primitives under run(), exposed one by one for kernel-level parity tests ------
  * (host buffers in, host buffers out; synchronous) */
@@ -359,8 +382,14 @@ enum {
  * Returns the average milliseconds per launch.  Used by bench tooling to sweep batch sizes. */
 int piehip_bench_ntt(piehip_handle h, uint32_t nlimbs, uint32_t mod_count, int flags, uint32_t iters, double *ms_per_launch);
 int piehip_set_profiling(piehip_handle h, int on);
-int piehip_profile_read(piehip_handle h, uint32_t *launches /*[NKERNELS]*/, double *ms /*[NKERNELS]*/,
-                        double *alg_bytes /*[NKERNELS]*/);
+/* piehip_profile_read_n fills the first min(n, PIEHIP_NKERNELS) entries of the caller's arrays: pass the length the caller was
+ * BUILT with, so that a library with more classes never writes past them (piehip_version() >= 101).
+ * piehip_profile_read is the entry point of version 100 and keeps that version's contract: exactly PIEHIP_NKERNELS_V100 = 12
+ * entries, the kernel classes only.  Class 12 (PIEHIP_K_EVENT_PAIR) is not a kernel -- it is what an event bracket reads with
+ * nothing between its two events -- and must not be added to a sum of kernel times. */
+#define PIEHIP_NKERNELS_V100 12
+int piehip_profile_read_n(piehip_handle h, uint32_t n, uint32_t *launches /*[n]*/, double *ms /*[n]*/, double *alg_bytes /*[n]*/);
+int piehip_profile_read(piehip_handle h, uint32_t *launches /*[12]*/, double *ms /*[12]*/, double *alg_bytes /*[12]*/);
 const char *piehip_kernel_name(int k);
 
 #ifdef __cplusplus

@@ -99,6 +99,13 @@ SYMBOLS = {
     "piehip_client_decrypt": (C.c_int, [C.c_void_p, u64p, u64p, C.c_uint32, C.c_uint32, i64p]),
     "piehip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "piehip_profile_read": (C.c_int, [C.c_void_p, u32p, f64p, f64p]),
+    "piehip_profile_read_n": (C.c_int, [C.c_void_p, C.c_uint32, u32p, f64p, f64p]),
+    "piehip_set_transform_slots": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "piehip_get_transform_slots": (C.c_int, [C.c_void_p, u32p, u32p]),
+    "piehip_upload_turn_wait": (C.c_int, [C.c_void_p, f64p, f64p, u64p]),
+    "piehip_rccl_wait": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "piehip_rccl_abort": (C.c_int, [C.c_void_p]),
+    "piehip_rccl_agree": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_uint32]),
 }
 
 _lib = None

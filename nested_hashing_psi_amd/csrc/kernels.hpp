@@ -34,7 +34,15 @@ struct NttPlan {
     const DevConsts *dc;  // device pointer
     u32 N, logN;
     u32 num_cus;
+    u32 max_slots = 0;    // piehip_set_transform_slots: cap on the persistent transform grids (workgroups), 0 = every slot
     bool force_generic;   // tests: route every size through the radix-2 LDS kernel
+    // CUs the persistent transform grids may fill (two workgroup slots of 512 threads, or one of 1024, per CU)
+    u32 transform_cus() const
+    {
+        if (!max_slots) return num_cus;
+        const u32 c = (max_slots + 1) / 2;
+        return c < num_cus ? (c ? c : 1u) : num_cus;
+    }
 };
 
 // In-place negacyclic NTT over `nlimbs` limbs [nlimbs][N]; limb i uses modulus mod_base + i % mod_count.

@@ -144,7 +144,7 @@ bool launch_ntt_digits(const NttPlan &pl, const u64 *d2, u64 *dig, u32 nb, u32 L
 {
     if (pl.force_generic || !pl.twp || !pl.twc || ntt_fast_s0(pl.logN) != 0) return false;
     if (sigma && ntt16_applies(pl, folded_layout)) return false;  // the lane order is the 16-coefficient kernel's: digits kernel + its transform
-    return launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, 0, dig, nb * L * L, 0, L, false, sigma, pl.num_cus, st, d2, L,
+    return launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, 0, dig, nb * L * L, 0, L, false, sigma, pl.transform_cus(), st, d2, L,
                            (sigma && folded_layout) ? 1u : 0u);
 }
 
@@ -166,7 +166,7 @@ void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_
         if (ex) exf = *ex;
         exf.folded = true;
         (void)launch_ntt_fast(pl.twp, pl.twc_fold, pl.dc, pl.N, pl.logN, 1, data, nlimbs, mod_base, mod_count, inverse, sigma,
-                              pl.num_cus, st, nullptr, 0, 0, &exf);
+                              pl.transform_cus(), st, nullptr, 0, 0, &exf);
         return;
     }
     NttArgs a;
@@ -197,10 +197,10 @@ void launch_ntt(const NttPlan &pl, u64 *data, u32 nlimbs, u32 mod_base, u32 mod_
     if (!inverse) {
         for (u32 ms = 1; ms < (1u << a.s0); ms <<= 1)
             hipLaunchKernelGGL(ntt_global_stage<false>, ggrid, dim3(256), 0, st, a, ms, 0u);
-        if (!(fast_ok && launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, a.s0, data, nlimbs, mod_base, mod_count, false, sigma, pl.num_cus, st, nullptr, 0, 0, ex)))
+        if (!(fast_ok && launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, a.s0, data, nlimbs, mod_base, mod_count, false, sigma, pl.transform_cus(), st, nullptr, 0, 0, ex)))
             hipLaunchKernelGGL(ntt_lds_generic<false>, dim3(nlimbs << a.s0), dim3(threads), lds, st, a);
     } else {
-        if (!(fast_ok && launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, a.s0, data, nlimbs, mod_base, mod_count, true, sigma, pl.num_cus, st, nullptr, 0, 0, ex)))
+        if (!(fast_ok && launch_ntt_fast(pl.twp, pl.twc, pl.dc, pl.N, pl.logN, a.s0, data, nlimbs, mod_base, mod_count, true, sigma, pl.transform_cus(), st, nullptr, 0, 0, ex)))
             hipLaunchKernelGGL(ntt_lds_generic<true>, dim3(nlimbs << a.s0), dim3(threads), lds, st, a);
         for (u32 ms = (1u << a.s0) >> 1; ms >= 1; ms >>= 1)
             hipLaunchKernelGGL(ntt_global_stage<true>, ggrid, dim3(256), 0, st, a, ms, ms == 1 ? 1u : 0u);

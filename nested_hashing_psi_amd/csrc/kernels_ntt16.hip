@@ -90,9 +90,9 @@ bool launch_ntt16(const NttPlan &pl, bool folded, u64 *data, u32 nlimbs, u32 mod
     }
     const bool lift = a.lift_first != ~0u;
     if (slice_log == 14)
-        launch_ntt16_t<14>(a, inverse, lift, pl.num_cus, st);
+        launch_ntt16_t<14>(a, inverse, lift, pl.transform_cus(), st);
     else
-        launch_ntt16_t<13>(a, inverse, lift, pl.num_cus, st);
+        launch_ntt16_t<13>(a, inverse, lift, pl.transform_cus(), st);
     return true;
 }
 

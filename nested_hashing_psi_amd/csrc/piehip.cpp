@@ -206,7 +206,7 @@ void enqueue_mul(piehip_ctx *h, MulWs &w, const u64 *x, size_t sx, const u64 *y,
 // =================================================================================================
 extern "C" {
 
-int piehip_version(void) { return 100; }
+int piehip_version(void) { return 101; }   // 101: piehip_profile_read_n, piehip_set_transform_slots, piehip_upload_turn_wait, piehip_rccl_abort
 const char *piehip_last_error(void) { return g_err.c_str(); }
 const char *piehip_kernel_name(int k) { return (k >= 0 && k < PIEHIP_NKERNELS) ? KNAMES[k] : "?"; }
 
@@ -485,6 +485,14 @@ int piehip_load_relin_key(piehip_handle h, const uint64_t *evk)
         launch_permute(h->hp.N, h->d_evk, h->d_sigma_inv, h->d_evk_sigma, h->hp.L * 2 * h->hp.L, h->stream);
         HIPCHK(hipStreamSynchronize(h->stream));
     }
+    // per-query key slots (piehip_load_relin_key_q) that no query loaded hold a COPY of the handle's key: they follow it
+    for (u32 i = 0; i < h->evkq_n && h->d_evkq; i++) {
+        if (h->evkq_loaded >> i & 1) continue;
+        HIPCHK(hipMemcpyAsync(h->d_evkq + i * words, h->d_evk, words * sizeof(u64), hipMemcpyDeviceToDevice, h->stream));
+        if (h->sigma_on && h->d_evkq_sigma)
+            HIPCHK(hipMemcpyAsync(h->d_evkq_sigma + i * words, h->d_evk_sigma, words * sizeof(u64), hipMemcpyDeviceToDevice, h->stream));
+    }
+    if (h->d_evkq) HIPCHK(hipStreamSynchronize(h->stream));
     return PIEHIP_OK;
 }
 
@@ -1392,6 +1400,22 @@ int piehip_set_run_streams(piehip_handle h, uint32_t n)
 {
     NEED_RO(h);
     h->run_streams = n;
+    return PIEHIP_OK;
+}
+
+int piehip_set_transform_slots(piehip_handle h, uint32_t n)
+{
+    NEED_RO(h);
+    h->plan.max_slots = n;
+    drop_graph(h);   // a captured run() has the old grids baked in
+    return PIEHIP_OK;
+}
+
+int piehip_get_transform_slots(piehip_handle h, uint32_t *n, uint32_t *device_slots)
+{
+    if (!h) return fail(PIEHIP_EINVAL, "null handle");
+    if (n) *n = h->plan.max_slots;
+    if (device_slots) *device_slots = 2 * h->plan.num_cus;
     return PIEHIP_OK;
 }
 

@@ -107,6 +107,8 @@ struct piehip_ctx {
     bool stage_open = false;                      // piehip_stage_*: the uploads of the next run()'s queries have begun
     u64 *pin_up_flag = nullptr;                   // page-locked word: sequence number of the last query of this handle whose uploads have
     u64 up_seq = 0;                               // left host memory (written by a one-thread kernel behind them); the next number
+    u64 up_turn_wait_ns = 0;                      // how long the last staging sequence waited for its turn on the device's link
+    u64 up_turn_wait_total_ns = 0, up_turn_waits = 0;   // ... and all of them so far (piehip_upload_turn_wait)
     u64 *host_results = nullptr;                  // set while piehip_run_staged enqueues: every queue group downloads its slice there
     u64 *pin_res = nullptr;                       // [b][nq][2][L][N]
     size_t pin_idx_words = 0, pin_res_words = 0;

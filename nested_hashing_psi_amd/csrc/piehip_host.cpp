@@ -35,30 +35,80 @@
 using namespace piehip;
 
 namespace {
-struct LastUpload {
-    const volatile u64 *flag = nullptr;   // the uploading handle's page-locked word
-    u64 seq = 0;                          // ... reads >= seq once that query's uploads are done
+// the page-locked word of a handle, shared with whoever still polls it (a handle may be destroyed while another waits its turn)
+struct UpWord {
+    u64 *w = nullptr;
+    ~UpWord()
+    {
+        if (w) (void)hipHostFree(w);
+    }
+};
+// Per DEVICE (the upload order is a matter of one device's PCIe link; until r05 one process-wide mutex was held while polling, so a
+// host thread waiting for device 0's word also blocked staging, hand-over and destruction of handles on every other device):
+//   turn   held by the one staging thread that waits for its turn -- the others of this device queue up behind it, nobody jumps
+//   m      guards `last`; never held while waiting
+struct DeviceUploads {
+    std::mutex turn, m;
+    std::shared_ptr<UpWord> flag;   // the word of the handle that handed a query over last ...
+    u64 seq = 0;                    // ... reads >= seq once that query's uploads are done
     const piehip_ctx *owner = nullptr;
 };
-std::mutex g_up_mutex;
-std::map<int, LastUpload> g_last_up;   // per device
+std::mutex g_up_map_mutex;
+std::map<int, std::unique_ptr<DeviceUploads>> g_up;   // per device; entries live as long as the process
+DeviceUploads &device_uploads(int device)
+{
+    std::lock_guard<std::mutex> lock(g_up_map_mutex);
+    std::unique_ptr<DeviceUploads> &p = g_up[device];
+    if (!p) p.reset(new DeviceUploads);
+    return *p;
+}
+struct UpWordHolder {   // piehip_ctx keeps the raw pointer (piehip_ctx.hpp is plain data); the owning reference lives here
+    std::mutex m;
+    std::map<const piehip_ctx *, std::shared_ptr<UpWord>> of;
+} g_words;
 }  // namespace
 
 // the first piece of a staging sequence waits (on the host) for the query another handle handed over last on this device
 static int upload_turn(piehip_ctx *h)
 {
     if (!h->pin_up_flag) {
-        HIPCHK(hipHostMalloc((void **)&h->pin_up_flag, 64, hipHostMallocPortable));
-        *h->pin_up_flag = 0;
+        // coherent: the word is written by a kernel (system-scope release) and polled by the host while that stream keeps running
+        std::shared_ptr<UpWord> wd(new UpWord);
+        HIPCHK(hipHostMalloc((void **)&wd->w, 64, hipHostMallocPortable | hipHostMallocCoherent));
+        *wd->w = 0;
+        h->pin_up_flag = wd->w;
+        std::lock_guard<std::mutex> lock(g_words.m);
+        g_words.of[h] = wd;
     }
-    std::lock_guard<std::mutex> lock(g_up_mutex);   // (held while waiting: the word's owner cannot free it, nobody jumps the queue)
-    const LastUpload last = g_last_up[h->device];
-    if (last.flag && last.owner != h) {
+    DeviceUploads &du = device_uploads(h->device);
+    std::lock_guard<std::mutex> turn(du.turn);
+    std::shared_ptr<UpWord> flag;
+    u64 seq = 0;
+    {
+        std::lock_guard<std::mutex> lock(du.m);
+        if (du.owner != h) flag = du.flag, seq = du.seq;
+    }
+    h->up_turn_wait_ns = 0;
+    if (flag) {
         const auto t0 = std::chrono::steady_clock::now();
-        while (__atomic_load_n(last.flag, __ATOMIC_ACQUIRE) < last.seq) {
+        bool late = false;
+        while (__atomic_load_n((const volatile u64 *)flag->w, __ATOMIC_ACQUIRE) < seq) {
             std::this_thread::yield();
-            // a stream that never gets there (a failed launch) must not hang the other handles: order is a matter of speed only
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                late = true;
+                break;
+            }
+        }
+        const u64 ns = (u64)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        h->up_turn_wait_ns = ns;
+        h->up_turn_wait_total_ns += ns;
+        h->up_turn_waits++;
+        if (late) {
+            // the other handle's stream never reached its flag kernel: forget that hand-over (the next sequence must not pay
+            // five seconds again) and tell the caller -- the upload order is broken, and so, most likely, is the device
+            std::lock_guard<std::mutex> lock(du.m);
+            if (du.flag == flag && du.seq == seq) du.flag.reset(), du.owner = nullptr;
+            return fail(PIEHIP_EHIP, "staging: the query another handle of this device handed over 5 s ago has not left host memory");
         }
     }
     return PIEHIP_OK;
@@ -68,9 +118,18 @@ static int upload_handed_over(piehip_ctx *h)
 {
     void *dev = nullptr;
     HIPCHK(hipHostGetDevicePointer(&dev, h->pin_up_flag, 0));
-    launch_host_flag((u64 *)dev, ++h->up_seq, h->stream);
-    std::lock_guard<std::mutex> lock(g_up_mutex);
-    g_last_up[h->device] = LastUpload{h->pin_up_flag, h->up_seq, h};
+    (void)hipGetLastError();
+    launch_host_flag((u64 *)dev, h->up_seq + 1, h->stream);
+    HIPCHK(hipGetLastError());   // a launch that failed never sets the word: nobody may be told to wait for it
+    ++h->up_seq;
+    std::shared_ptr<UpWord> wd;
+    {
+        std::lock_guard<std::mutex> lock(g_words.m);
+        wd = g_words.of[h];
+    }
+    DeviceUploads &du = device_uploads(h->device);
+    std::lock_guard<std::mutex> lock(du.m);
+    du.flag = wd, du.seq = h->up_seq, du.owner = h;
     return PIEHIP_OK;
 }
 
@@ -80,11 +139,13 @@ void free_host_path(piehip_ctx *h)
 {
     if (h->pin_up_flag) {
         {
-            std::lock_guard<std::mutex> lock(g_up_mutex);
-            auto it = g_last_up.find(h->device);
-            if (it != g_last_up.end() && it->second.owner == h) g_last_up.erase(it);
+            DeviceUploads &du = device_uploads(h->device);
+            std::lock_guard<std::mutex> lock(du.m);
+            if (du.owner == h) du.flag.reset(), du.owner = nullptr;
         }
-        (void)hipHostFree(h->pin_up_flag);
+        // (a thread that is polling the word right now holds a reference of its own: the page is freed when it lets go)
+        std::lock_guard<std::mutex> lock(g_words.m);
+        g_words.of.erase(h);
         h->pin_up_flag = nullptr;
     }
     for (QueryStage &s : h->qstage) {
@@ -97,6 +158,15 @@ void free_host_path(piehip_ctx *h)
 }
 
 }  // namespace piehip
+
+extern "C" int piehip_upload_turn_wait(piehip_handle h, double *last_ms, double *total_ms, uint64_t *waits)
+{
+    if (!h) return fail(PIEHIP_EINVAL, "null handle");
+    if (last_ms) *last_ms = (double)h->up_turn_wait_ns * 1e-6;
+    if (total_ms) *total_ms = (double)h->up_turn_wait_total_ns * 1e-6;
+    if (waits) *waits = h->up_turn_waits;
+    return PIEHIP_OK;
+}
 
 // One run()'s uploads, piece by piece (piehip_stage_*): every piece is one asynchronous copy from host memory on the handle's
 // stream, i.e. behind whatever the handle still has in flight (an earlier run that reads the input buffers included).

@@ -13,7 +13,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <mutex>
+#include <thread>
 
 using namespace piehip;
 
@@ -30,6 +32,10 @@ struct Rccl {
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    // optional (a library without them still gathers; piehip_rccl_wait then only has its time-out, piehip_rccl_agree is refused)
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     std::string error;
 };
 
@@ -69,6 +75,9 @@ const Rccl *rccl()
     BIND(Broadcast, "ncclBroadcast");
     BIND(GetErrorString, "ncclGetErrorString");
 #undef BIND
+    *(void **)(&r.CommAbort) = dlsym(r.lib, "ncclCommAbort");
+    *(void **)(&r.CommGetAsyncError) = dlsym(r.lib, "ncclCommGetAsyncError");
+    *(void **)(&r.AllReduce) = dlsym(r.lib, "ncclAllReduce");
     return &r;
 }
 
@@ -148,6 +157,103 @@ int piehip_rccl_destroy(piehip_handle h)
     h->comm_owned = false;
     h->comm_ranks = h->comm_rank = 0;
     return PIEHIP_OK;
+}
+
+// Giving up.  A collective is queued in the handle's stream and completes when every rank has queued its side; a rank that
+// never does (it died, it failed a precondition and returned before queueing anything, it is a programming error away from the
+// others) leaves its peers' streams blocked for ever -- the reference aborts the whole process on any error
+// (BatchedFHEHIPPIE.cpp:15,20), a hung group of server processes is worse.  So nobody waits without a bound:
+//   piehip_rccl_wait    piehip_sync with a time-out: polls the handle's stream and the communicator's asynchronous error state;
+//                       when the time is up (or RCCL reports a failed peer) it ABORTS the communicator -- which releases the
+//                       blocked stream -- and returns PIEHIP_EHIP.  The communicator is gone afterwards.
+//   piehip_rccl_abort   the same on purpose: a rank that cannot take part any more (an exception on its way out) tears its
+//                       side down so that its peers' waits end at once instead of at their time-out.
+//   piehip_rccl_agree   one word from every rank, everybody learns whether ALL said yes (an all-reduce + wait): the ranks of a
+//                       server call it at the end of a phase (database built? key loaded?) so that a failure on one of them
+//                       ends the session everywhere before anybody enters a collective the failed rank will not join.
+static int abort_comm(piehip_ctx *h, const Rccl *R)
+{
+    if (!h->comm) return PIEHIP_OK;
+    if (R && R->CommAbort && h->comm_owned) (void)R->CommAbort((ncclComm_t)h->comm);
+    h->comm = nullptr;
+    h->comm_owned = false;
+    h->comm_ranks = h->comm_rank = 0;
+    return PIEHIP_OK;
+}
+
+int piehip_rccl_abort(piehip_handle h)
+{
+    if (!h) return fail(PIEHIP_EINVAL, "null handle");
+    if (!h->comm) return PIEHIP_OK;
+    HIPCHK(hipSetDevice(h->device));
+    return abort_comm(h, rccl());
+}
+
+int piehip_rccl_wait(piehip_handle h, uint32_t timeout_ms)
+{
+    NEED_RO(h);
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->comm) {   // nothing of RCCL's can be in the stream: a plain wait
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return PIEHIP_OK;
+    }
+    const Rccl *R = rccl();
+    if (!R) return no_rccl();
+    const auto t0 = std::chrono::steady_clock::now();
+    std::string why;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return fail(PIEHIP_EHIP, std::string("rccl_wait: ") + hipGetErrorString(q));
+        ncclResult_t ae = ncclSuccess;
+        if (R->CommGetAsyncError && R->CommGetAsyncError((ncclComm_t)h->comm, &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress) {
+            why = std::string("rccl_wait: the communicator reports ") + R->GetErrorString(ae);
+            break;
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) {
+            why = "rccl_wait: timed out after " + std::to_string(timeout_ms) + " ms -- a rank of the server group did not join the collective";
+            break;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    if (why.empty()) {
+        // (the stream has drained; a transfer that FAILED also drains it: ask once more)
+        ncclResult_t ae = ncclSuccess;
+        if (R->CommGetAsyncError && R->CommGetAsyncError((ncclComm_t)h->comm, &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress)
+            why = std::string("rccl_wait: the communicator reports ") + R->GetErrorString(ae);
+        else
+            return PIEHIP_OK;
+    }
+    abort_comm(h, R);
+    (void)hipStreamSynchronize(h->stream);   // the abort released whatever of the collective sat in the stream
+    return fail(PIEHIP_EHIP, why + " (communicator aborted)");
+}
+
+int piehip_rccl_agree(piehip_handle h, int ok, int *all_ok, uint32_t timeout_ms)
+{
+    NEED(h);
+    if (!all_ok) return fail(PIEHIP_EINVAL, "null result");
+    if (!h->comm) return fail(PIEHIP_ESTATE, "rccl_agree: no communicator");
+    const Rccl *R = rccl();
+    if (!R) return no_rccl();
+    if (!R->AllReduce) return fail(PIEHIP_EHIP, "rccl_agree: this RCCL has no ncclAllReduce");
+    HIPCHK(hipSetDevice(h->device));
+    Tmp tmp(h);
+    TMPGET(d_word, 1);
+    int32_t *pin = nullptr;
+    HIPCHK(hipHostMalloc((void **)&pin, 64, hipHostMallocPortable));
+    pin[0] = ok ? 1 : 0;
+    int rc = PIEHIP_OK;
+    do {
+        if (hipMemcpyAsync(d_word, pin, 4, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail(PIEHIP_EHIP, "rccl_agree: upload"); break; }
+        const ncclResult_t r = R->AllReduce(d_word, d_word, 1, ncclInt32, ncclMin, (ncclComm_t)h->comm, h->stream);
+        if (r != ncclSuccess) { rc = fail(PIEHIP_EHIP, std::string("rccl_agree: ") + R->GetErrorString(r)); break; }
+        if (hipMemcpyAsync(pin, d_word, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess) { rc = fail(PIEHIP_EHIP, "rccl_agree: download"); break; }
+        rc = piehip_rccl_wait(h, timeout_ms);
+    } while (0);
+    if (rc == PIEHIP_OK) *all_ok = pin[0] != 0;
+    (void)hipHostFree(pin);
+    return rc;
 }
 
 // [lo, hi): the bin layers of rank r of G (contiguous, sizes differ by at most one: shard.bin_slice, ShardedBatchedFHEHIPPIE)

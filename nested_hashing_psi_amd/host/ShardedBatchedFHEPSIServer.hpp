@@ -14,9 +14,17 @@
 //            reference's timer (.cpp:98-106): the query goes to every rank over xGMI (piehip_rccl_broadcast_query), every rank
 //            runs its layers (piehip_run), the result ciphertexts are gathered to rank 0 (piehip_gather_results -- the
 //            evaluation's only exchange) and come down to host memory; rank 0 answers the client (.cpp:143-152)
-// Error handling is the reference's: exceptions end the process (a worker that dies takes the communicator with it).
+// Error handling is the reference's -- exceptions end the process (BatchedFHEHIPPIE.cpp:15,20 throw, nothing catches) -- made safe
+// for a GROUP of processes: a collective only completes when every rank joins it, so
+//   * at the end of the offline phase the ranks agree that everybody built its slice (piehip_rccl_agree): a rank whose build threw
+//     says no on its way out and all of them end the session there, before anybody waits in a collective for it;
+//   * every wait for a collective has a bound (piehip_rccl_wait, collectiveTimeoutMs): a rank that died in the online phase costs
+//     its peers that time-out and an exception, not a hung group of server processes;
+//   * a rank that leaves run() by exception aborts its side of the communicator first (piehip_rccl_abort), which ends its peers'
+//     waits at once.
 #pragma once
 #include <chrono>
+#include <exception>
 #include <memory>
 #include <random>
 
@@ -46,12 +54,20 @@ public:
 
     void run()  // PSIServer.hpp:66-87
     {
-        runSetUpPhase();
-        if (rank == 0) wire::signalPhaseOver(fd);
-        runOfflinePhase();
-        if (rank == 0) wire::signalPhaseOver(fd);
-        runOnlinePhase();
+        try {
+            runSetUpPhase();
+            if (rank == 0) wire::signalPhaseOver(fd);
+            runOfflinePhase();
+            if (rank == 0) wire::signalPhaseOver(fd);
+            runOnlinePhase();
+        } catch (...) {
+            if (cc) (void)piehip_rccl_abort(cc->handle());   // the peers' waits end now, not at their time-out
+            throw;
+        }
     }
+
+    bool failOfflineForTesting = false;     // this rank's database build "fails": the group must end the session, not hang
+    uint32_t collectiveTimeoutMs = 30000;   // bound on every wait for the other ranks (piehip_rccl_wait / piehip_rccl_agree)
 
     long long offlineComputation = 0, onlineComputation = 0;  // microseconds (rank 0: PSIServer.hpp:89-103)
 
@@ -111,19 +127,32 @@ public:
     void runOfflinePhase()
     {
         const auto begin = std::chrono::steady_clock::now();
-        if (hi > lo) {
+        std::exception_ptr failed;
+        try {
+            if (hi <= lo) throw std::runtime_error("more ranks than bin layers: start at most eachBinSize server processes");
+            if (failOfflineForTesting) throw std::runtime_error("offline phase failed on this rank (test)");
             PieContext::check(piehip_build_db_bins(cc->handle(), serverSet.data(), serverSet.size(), ht.numberOfSimpleHashFunctions,
                                                    ht.eachSimpleTableSize, ht.numberOfCuckooHashFunctions, ht.maxItemsPerPosition,
                                                    ht.eachCuckooTableSize, hashSeed, seeds[0], seeds[1], seeds[2], lo, hi));
             PieContext::check(piehip_sync(cc->handle()));
-        } else {
-            throw std::runtime_error("more ranks than bin layers: start at most eachBinSize server processes");
+        } catch (...) {
+            failed = std::current_exception();
         }
+        // every rank says whether its slice is ready; a no anywhere ends the session everywhere (a Cuckoo insertion that failed
+        // -- CuckooHashTable.cpp:113 -- fails on every rank alike; out of memory on one GPU does not)
+        int allBuilt = 0;
+        PieContext::check(piehip_rccl_agree(cc->handle(), failed ? 0 : 1, &allBuilt, collectiveTimeoutMs));
+        if (failed) std::rethrow_exception(failed);
+        if (!allBuilt) throw std::runtime_error("another rank of the server group could not build its slice of the database");
         // one evaluation of an all-zero query through the whole online path (code objects, queues, the communicator's first
-        // collective) while nobody waits for it
+        // collective) while nobody waits for it.  Only rank 0 stages queries from host memory: the workers get their device-side
+        // input buffers and run queues, no page-locked index matrix (29 MiB at C3 that nothing would ever write)
         const size_t ct = ctWords();
         uint64_t *pinIdx = nullptr, *pinMinus = nullptr, *pinRes = nullptr;
-        PieContext::check(piehip_host_buffers(cc->handle(), &pinIdx, &pinMinus, &pinRes));
+        if (rank == 0)
+            PieContext::check(piehip_host_buffers(cc->handle(), &pinIdx, &pinMinus, &pinRes));
+        else
+            PieContext::check(piehip_host_buffers(cc->handle(), nullptr, nullptr, nullptr));
         if (rank == 0) {
             const uint32_t K = ht.numberOfCuckooHashFunctions, E = ht.eachCuckooTableSize;
             std::memset(pinMinus, 0, ct * sizeof(uint64_t));
@@ -179,7 +208,7 @@ private:
         PieContext::check(piehip_run(cc->handle()));
         uint64_t *gathered = nullptr;  // rank 0: page-locked, owned by the library, [b][2][L][N] in bin order
         PieContext::check(piehip_gather_results_host(cc->handle(), b, 0, &gathered));
-        PieContext::check(piehip_sync(cc->handle()));
+        PieContext::check(piehip_rccl_wait(cc->handle(), collectiveTimeoutMs));   // piehip_sync with a bound
         return gathered;
     }
 

@@ -188,6 +188,19 @@ class PieContext:
     def rccl_destroy(self):
         _check(lib().piehip_rccl_destroy(self._h))
 
+    def rccl_wait(self, timeout_ms=30000):
+        """piehip_sync with a time-out: a rank that never joins a collective aborts the communicator here instead of hanging the group"""
+        _check(lib().piehip_rccl_wait(self._h, int(timeout_ms)))
+
+    def rccl_abort(self):
+        _check(lib().piehip_rccl_abort(self._h))
+
+    def rccl_agree(self, ok, timeout_ms=30000):
+        """True when every rank of the communicator passed a true `ok` (piehip_rccl_agree)"""
+        out = C.c_int()
+        _check(lib().piehip_rccl_agree(self._h, int(bool(ok)), C.byref(out), int(timeout_ms)))
+        return bool(out.value)
+
     def rotation_galois(self, index):
         """Galois element 5^index mod 2N of the row rotation by `index` (EvalAtIndex convention: > 0 rotates left)"""
         g = C.c_uint32()
@@ -217,6 +230,23 @@ class PieContext:
         """run() spreads the bin layers over up to n HIP streams (0 = default, 1 = serial on the handle's stream)"""
         _check(lib().piehip_set_run_streams(self._h, int(n)))
 
+    def set_transform_slots(self, n):
+        """cap the persistent transform grids at n workgroups (0 = every slot of the device): leaves CUs to RCCL's kernels on a sharded
+        server (piehip_set_transform_slots); results do not depend on it"""
+        _check(lib().piehip_set_transform_slots(self._h, int(n)))
+
+    def transform_slots(self):
+        """(cap, slots of the device)"""
+        n, d = C.c_uint32(), C.c_uint32()
+        _check(lib().piehip_get_transform_slots(self._h, C.byref(n), C.byref(d)))
+        return int(n.value), int(d.value)
+
+    def upload_turn_wait(self):
+        """how long this handle's staging sequences waited for their turn on the PCIe link: (last ms, total ms, waits)"""
+        a, b, n = C.c_double(), C.c_double(), C.c_uint64()
+        _check(lib().piehip_upload_turn_wait(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return float(a.value), float(b.value), int(n.value)
+
     def set_graph(self, on):
         """run() as one captured hipGraph (piehip_set_graph)"""
         _check(lib().piehip_set_graph(self._h, int(on)))
@@ -228,7 +258,7 @@ class PieContext:
         n = np.zeros(NKERNELS, dtype=np.uint32)
         ms = np.zeros(NKERNELS, dtype=np.float64)
         by = np.zeros(NKERNELS, dtype=np.float64)
-        _check(lib().piehip_profile_read(self._h, n.ctypes.data_as(u32p), ms.ctypes.data_as(f64p), by.ctypes.data_as(f64p)))
+        _check(lib().piehip_profile_read_n(self._h, NKERNELS, n.ctypes.data_as(u32p), ms.ctypes.data_as(f64p), by.ctypes.data_as(f64p)))
         names = [lib().piehip_kernel_name(k).decode() for k in range(NKERNELS)]
         return {names[k]: dict(launches=int(n[k]), ms=float(ms[k]), alg_bytes=float(by[k])) for k in range(NKERNELS) if n[k]}
 

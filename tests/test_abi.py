@@ -142,7 +142,8 @@ def test_cpp_server_harness_compiles(built, tmp_path):
 def test_cpp_sharded_server_compiles(built, tmp_path):
     """host/ShardedBatchedFHEPSIServer.hpp -- one process per GPU, the query distribution and the final gather over RCCL behind the
     C ABI (piehip_rccl_*, piehip_gather_results*) -- builds warning-free against the library alone: no RCCL headers, no torch.
-    It runs with one rank in tests/test_sharding_gpu.py::test_cpp_server_over_rccl_one_rank."""
+    It runs with one rank over RCCL in tests/test_sharding_gpu.py::test_cpp_server_over_rccl_one_rank and with 2-5 ranks over the test-only
+    stand-in transport in tests/test_rccl_ranks.py."""
     import subprocess
     libdir = os.path.join(ROOT, "nested_hashing_psi_amd")
     exe = str(tmp_path / "sharded_server_main")
@@ -152,6 +153,33 @@ def test_cpp_sharded_server_compiles(built, tmp_path):
     # the library does not LINK against RCCL (bound at run time: a one-GPU deployment never loads it)
     needed = subprocess.check_output(["readelf", "-d", os.path.join(libdir, "libpiehip.so")]).decode()
     assert "rccl" not in needed
+
+
+def test_rccl_stand_in_is_test_infrastructure_only(built, tmp_path):
+    """tests/fake_rccl (the transport that lets several ranks share the one GPU of the test box, tests/test_rccl_ranks.py) and the
+    native multi-rank program compile here; the PACKAGE ships no RCCL of any kind -- the stand-in exists only as source under tests/
+    and as a library in a test's temporary directory -- and nothing in the product names it."""
+    import subprocess
+    libdir = os.path.join(ROOT, "nested_hashing_psi_amd")
+    fake = str(tmp_path / "librccl.so.1")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", fake,
+                           os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp"), "-Wl,-soname,librccl.so.1", "-L/opt/rocm/lib",
+                           "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-lpthread"])
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", fake]).decode()
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommAbort", "ncclCommGetAsyncError", "ncclGroupStart",
+                 "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclBroadcast", "ncclAllReduce", "ncclGetErrorString"):
+        assert (" T " + name) in syms, name
+    exe = str(tmp_path / "rccl_ranks_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "rccl_ranks_main.cpp"),
+                           "-L" + libdir, "-lpiehip", "-Wl,-rpath," + libdir])
+    assert subprocess.call([exe]) == 2
+    for dirpath, _, files in os.walk(libdir):
+        if os.sep + "build" in dirpath or "__pycache__" in dirpath:
+            continue
+        for f in files:
+            assert "rccl" not in f.lower() or f == "piehip_rccl.cpp", "the package ships %s" % os.path.join(dirpath, f)
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", ".inc")) or f == "Makefile":
+                assert "fake_rccl" not in open(os.path.join(dirpath, f), errors="replace").read(), os.path.join(dirpath, f)
 
 
 def test_rccl_entry_points_check_their_arguments(built):
@@ -170,6 +198,8 @@ def test_rccl_entry_points_check_their_arguments(built):
     assert all(shard.bin_slice(14, r, 8) == tuple(_slice(L, 14, 8, r)) for r in range(8))   # the same partition as the Python harness
     assert L.piehip_rccl_bin_slice(14, 8, 8, C.byref(lo), C.byref(hi)) == -1
     assert L.piehip_gather_results(None, 14, 0, None) == -1 and L.piehip_rccl_broadcast_query(None, 0) == -1
+    ok = C.c_int()
+    assert L.piehip_rccl_wait(None, 10) == -1 and L.piehip_rccl_abort(None) == -1 and L.piehip_rccl_agree(None, 1, C.byref(ok), 10) == -1
 
 
 def _slice(L, b, G, r):

@@ -766,6 +766,108 @@ def test_query_batches(ob, pie, N, L, t, K, E, b, nqs):
     cc.close()
 
 
+def test_key_slots_follow_the_handles_key(ob, pie):
+    """piehip_load_relin_key_q gives query q its client's EvalMult key; queries without one use the HANDLE's key -- also when that key
+    is loaded or replaced AFTER the per-query slots exist (the slots held a copy taken once, a later
+    piehip_load_relin_key left them stale and run() relinearised with the old key, silently)."""
+    N, L, t, K, E, b = 4096, 2, T16, 2, 3, 3
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(2025)
+    q = cc.q
+    db, masks = rand_limbs(rng, q, (K, b, E), N), rand_limbs(rng, q, (b,), N)
+    key_old, key_new, key_a = (rand_limbs(rng, q, (L, 2), N) for _ in range(3))
+    queries = [(rand_limbs(rng, q, (K, E, 2), N), rand_limbs(rng, q, (2,), N)) for _ in range(2)]
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    op.setQueryBatch(2)
+    for i, (idx, minus) in enumerate(queries):
+        op.setIndex(idx, query=i)
+        op.setMinusCompareElement(minus, query=i)
+    # (1) a per-query key first, the handle's key afterwards: query 1 had NO key when the slots were made
+    cc.load_relin_key(key_a, query=0)
+    with pytest.raises(RuntimeError, match="key"):
+        op.run()
+    cc.load_relin_key(key_old)
+    op.run()
+    got = op.getResultList()
+    assert (got[0] == o.pie_run(*queries[0], db, masks, key_a)).all() and (got[1] == o.pie_run(*queries[1], db, masks, key_old)).all()
+    # (2) the handle's key replaced: query 1 follows it, query 0 keeps its own
+    cc.load_relin_key(key_new)
+    op.run()
+    got = op.getResultList()
+    assert (got[0] == o.pie_run(*queries[0], db, masks, key_a)).all() and (got[1] == o.pie_run(*queries[1], db, masks, key_new)).all()
+    cc.close()
+
+
+@pytest.mark.parametrize("N,L,t,K,E,b,nq", [(16384, 4, T32, 2, 3, 9, 2), (32768, 6, T32, 2, 2, 2, 1), (8192, 3, T32, 3, 3, 5, 3)])
+def test_transform_slots_do_not_change_results(ob, pie, N, L, t, K, E, b, nq):
+    """piehip_set_transform_slots caps the persistent transform grids (a sharded server leaves CUs to RCCL's kernels): every cap --
+    one workgroup, an odd number, fewer than the launch has slices, more than the device has slots -- gives the oracle's bits, on
+    one and two queues."""
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(N + b)
+    q = cc.q
+    db, masks, evk = rand_limbs(rng, q, (K, b, E), N), rand_limbs(rng, q, (b,), N), rand_limbs(rng, q, (L, 2), N)
+    cc.load_relin_key(evk)
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    if nq > 1:
+        op.setQueryBatch(nq)
+    queries = [(rand_limbs(rng, q, (K, E, 2), N), rand_limbs(rng, q, (2,), N)) for _ in range(nq)]
+    want = [o.pie_run(idx, minus, db, masks, evk) for idx, minus in queries]
+    for i, (idx, minus) in enumerate(queries):
+        op.setIndex(idx, query=i)
+        op.setMinusCompareElement(minus, query=i)
+    cap0, dev_slots = cc.transform_slots()
+    assert cap0 == 0 and dev_slots >= 2
+    for cap in (1, 7, 64, dev_slots - 32, 4 * dev_slots, 0):
+        cc.set_transform_slots(cap)
+        assert cc.transform_slots()[0] == cap
+        for streams in (0, 1):
+            cc.set_run_streams(streams)
+            op.run()
+            got = op.getResultList()
+            got = got[None] if nq == 1 else got
+            for i in range(nq):
+                assert (got[i] == want[i]).all(), "cap %d, %d queue(s), query %d" % (cap, streams, i)
+    cc.close()
+
+
+def test_profile_read_lengths(ob, pie):
+    """piehip_profile_read_n writes min(n, PIEHIP_NKERNELS) entries; piehip_profile_read is version 100's entry point and keeps that
+    version's twelve (a caller built against the old header passes arrays of twelve: ADVICE r04); piehip_version says which"""
+    import ctypes as C
+    from nested_hashing_psi_amd._lib import lib, u32p, f64p, NKERNELS
+    N, L, t, K, E, b = 4096, 2, T16, 2, 3, 3
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(5)
+    q = cc.q
+    cc.load_relin_key(rand_limbs(rng, q, (L, 2), N))
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=rand_limbs(rng, q, (K, b, E), N), preCalcRandomMask=rand_limbs(rng, q, (b,), N))
+    op.setIndex(rand_limbs(rng, q, (K, E, 2), N))
+    op.setMinusCompareElement(rand_limbs(rng, q, (2,), N))
+    cc.set_run_streams(1)
+    cc.set_profiling(True)
+    op.run()
+    assert lib().piehip_version() >= 101
+    prof = cc.profile()
+    assert prof["event_pair"]["launches"] >= 1 and prof["stage_a_mac"]["launches"] == 1
+    for entry, n in ((lib().piehip_profile_read, 12), (None, 5), (None, NKERNELS + 7)):
+        size = max(n, 12) + 4
+        cnt = np.full(size, 0xDEAD, dtype=np.uint32)
+        ms = np.full(size, -1.0)
+        by = np.full(size, -1.0)
+        if entry is not None:
+            assert entry(cc._h, cnt.ctypes.data_as(u32p), ms.ctypes.data_as(f64p), by.ctypes.data_as(f64p)) == 0
+        else:
+            assert lib().piehip_profile_read_n(cc._h, n, cnt.ctypes.data_as(u32p), ms.ctypes.data_as(f64p), by.ctypes.data_as(f64p)) == 0
+        filled = min(n, NKERNELS)
+        assert (cnt[filled:] == 0xDEAD).all() and (ms[filled:] == -1.0).all() and (by[filled:] == -1.0).all()
+        assert cnt[0] == 1 and (cnt[:filled] != 0xDEAD).all()
+    cc.set_profiling(False)
+    cc.close()
+
+
 @pytest.mark.parametrize("E,b", [(1, 1), (1, 3), (15, 2), (16, 3), (40, 5)])
 def test_run_shape_extremes(ob, pie, E, b):
     """one inner position, the last E of the carry-free accumulator (15), the first E of the 128-bit accumulator (16), a long
