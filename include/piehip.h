@@ -186,6 +186,11 @@ int piehip_run_staged(piehip_handle h, uint64_t *results);
 /* how long this handle's staging sequences waited (on the host) for their turn on the device's link: the last one, all of them,
  * and how many waited at all.  A wait that reaches 5 s returns PIEHIP_EHIP from the staging call instead of going on silently. */
 int piehip_upload_turn_wait(piehip_handle h, double *last_ms, double *total_ms, uint64_t *waits);
+/* measurement: with timing on, every host-memory query records three events on the handle's stream (first staged piece, uploads
+ * handed over, results down); after piehip_run_host_wait piehip_host_path_times gives the last query's upload time and the rest
+ * (evaluation + the result list's way down) -- which side of a slow query is slow */
+int piehip_set_host_path_timing(piehip_handle h, int on);
+int piehip_host_path_times(piehip_handle h, double *upload_ms, double *rest_ms);
 /* Stream order.  run() works on the handle's own queues (piehip_set_run_streams); it waits for the handle's stream
  * where it must (new inputs; the result buffer), and the handle's stream waits for the run in the next call of any
  * other entry point -- piehip_join() does only that, piehip_sync() also blocks the host.  Work queued on the handle's

@@ -103,6 +103,8 @@ SYMBOLS = {
     "piehip_set_transform_slots": (C.c_int, [C.c_void_p, C.c_uint32]),
     "piehip_get_transform_slots": (C.c_int, [C.c_void_p, u32p, u32p]),
     "piehip_upload_turn_wait": (C.c_int, [C.c_void_p, f64p, f64p, u64p]),
+    "piehip_set_host_path_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "piehip_host_path_times": (C.c_int, [C.c_void_p, f64p, f64p]),
     "piehip_rccl_wait": (C.c_int, [C.c_void_p, C.c_uint32]),
     "piehip_rccl_abort": (C.c_int, [C.c_void_p]),
     "piehip_rccl_agree": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_uint32]),

@@ -109,6 +109,10 @@ struct piehip_ctx {
     u64 up_seq = 0;                               // left host memory (written by a one-thread kernel behind them); the next number
     u64 up_turn_wait_ns = 0;                      // how long the last staging sequence waited for its turn on the device's link
     u64 up_turn_wait_total_ns = 0, up_turn_waits = 0;   // ... and all of them so far (piehip_upload_turn_wait)
+    // piehip_set_host_path_timing: three events per query on the handle's stream -- first staged piece, uploads handed over, results down
+    bool hp_timing = false;
+    hipEvent_t hp_ev[3] = {nullptr, nullptr, nullptr};
+    int hp_ev_state = 0;                          // 0 nothing recorded, 1 first piece, 2 handed over, 3 complete sequence recorded
     u64 *host_results = nullptr;                  // set while piehip_run_staged enqueues: every queue group downloads its slice there
     u64 *pin_res = nullptr;                       // [b][nq][2][L][N]
     size_t pin_idx_words = 0, pin_res_words = 0;

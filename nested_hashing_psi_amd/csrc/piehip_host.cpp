@@ -155,6 +155,11 @@ void free_host_path(piehip_ctx *h)
     }
     if (h->pin_res) (void)hipHostFree(h->pin_res);
     h->pin_res = nullptr;
+    for (hipEvent_t &e : h->hp_ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
+    h->hp_timing = false;
 }
 
 }  // namespace piehip
@@ -181,6 +186,10 @@ static int stage_begin(piehip_ctx *h, u32 q)
     int rc = upload_turn(h);
     if (rc) return rc;
     h->stage_open = true;
+    if (h->hp_timing) {
+        h->hp_ev_state = 0;
+        if (hipEventRecord(h->hp_ev[0], h->stream) == hipSuccess) h->hp_ev_state = 1;
+    }
     for (u32 i = 0; i < h->nq; i++) {
         h->qstage[i].minus = false;
         h->qstage[i].rows.assign(h->K, false);
@@ -319,6 +328,7 @@ int piehip_run_staged(piehip_handle h, uint64_t *results)
     mark_dirty(h);
     int rc = upload_handed_over(h);
     if (rc) return rc;
+    if (h->hp_timing && h->hp_ev_state == 1 && hipEventRecord(h->hp_ev[1], h->stream) == hipSuccess) h->hp_ev_state = 2;
     h->host_results = results;
     rc = piehip_run_into(h, h->d_out);
     h->host_results = nullptr;
@@ -348,7 +358,34 @@ int piehip_run_host_wait(piehip_handle h)
     if (!h) return fail(PIEHIP_EINVAL, "null handle");
     HIPCHK(hipSetDevice(h->device));
     join_pending(h);  // uploads, evaluation and downloads are all behind the handle's stream now
+    if (h->hp_timing && h->hp_ev_state == 2 && hipEventRecord(h->hp_ev[2], h->stream) == hipSuccess) h->hp_ev_state = 3;
     HIPCHK(hipStreamSynchronize(h->stream));
+    return PIEHIP_OK;
+}
+
+// Where a host-memory query spends its time ON THE DEVICE SIDE: events on the handle's stream at the first staged piece, behind the
+// last upload (piehip_run_staged) and behind the last download (piehip_run_host_wait).  upload_ms is the time the query's pieces
+// took to cross PCIe (from the moment the stream reached the first one), rest_ms the evaluation plus the result list's way down.
+int piehip_set_host_path_timing(piehip_handle h, int on)
+{
+    NEED_RO(h);
+    HIPCHK(hipSetDevice(h->device));
+    if (on && !h->hp_ev[0])
+        for (hipEvent_t &e : h->hp_ev) HIPCHK(hipEventCreate(&e));
+    h->hp_timing = on != 0;
+    h->hp_ev_state = 0;
+    return PIEHIP_OK;
+}
+
+int piehip_host_path_times(piehip_handle h, double *upload_ms, double *rest_ms)
+{
+    if (!h) return fail(PIEHIP_EINVAL, "null handle");
+    if (!h->hp_timing || h->hp_ev_state != 3) return fail(PIEHIP_ESTATE, "host_path_times: no complete timed query (piehip_set_host_path_timing, then stage / run_staged / run_host_wait)");
+    float a = 0, b = 0;
+    HIPCHK(hipEventElapsedTime(&a, h->hp_ev[0], h->hp_ev[1]));
+    HIPCHK(hipEventElapsedTime(&b, h->hp_ev[1], h->hp_ev[2]));
+    if (upload_ms) *upload_ms = a;
+    if (rest_ms) *rest_ms = b;
     return PIEHIP_OK;
 }
 

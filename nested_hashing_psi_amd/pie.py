@@ -247,6 +247,15 @@ class PieContext:
         _check(lib().piehip_upload_turn_wait(self._h, C.byref(a), C.byref(b), C.byref(n)))
         return float(a.value), float(b.value), int(n.value)
 
+    def set_host_path_timing(self, on):
+        _check(lib().piehip_set_host_path_timing(self._h, int(on)))
+
+    def host_path_times(self):
+        """(upload ms, evaluation + download ms) of the last host-memory query that ran with timing on"""
+        a, b = C.c_double(), C.c_double()
+        _check(lib().piehip_host_path_times(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
     def set_graph(self, on):
         """run() as one captured hipGraph (piehip_set_graph)"""
         _check(lib().piehip_set_graph(self._h, int(on)))
