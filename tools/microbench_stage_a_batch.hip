@@ -28,7 +28,7 @@ static void run(bool same_idx)
     for (int rep = 0; rep < NREP; rep++) {
         const u64 *db = g_db + (size_t)(rep % NBUF) * DBW;
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((stage_a_mad_batch_kernel<BPT, Q, DEPTH>), grid, dim3(TPB), 0, 0, g_dc, N, L, K, B, E, qs, db, g_acc, B, 0u, (u32)Q, 0u, tiles);
+        hipLaunchKernelGGL((stage_a_mad_batch_kernel<BPT, Q, DEPTH>), grid, dim3(TPB), 0, 0, g_dc, N, L, K, B, E, qs, db, g_acc, B, 0u, (u32)Q, 0u, tiles, StageAXOut{});
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -57,13 +57,9 @@ int main()
     for (int q = 0; q < 8; q++) { CK(hipMalloc(&g_idx[q], idw * 8)); CK(hipMemset(g_idx[q], 2 + q, idw * 8)); }
     for (int s = 0; s < 2; s++) {
         run<4, 2, 3>(s);
-        run<2, 2, 3>(s);
         run<2, 3, 3>(s);
         run<2, 3, 2>(s);
-        run<2, 4, 3>(s);
         run<2, 4, 2>(s);
-        run<2, 4, 4>(s);
-        run<1, 4, 3>(s);
     }
     return 0;
 }
