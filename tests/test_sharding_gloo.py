@@ -254,3 +254,95 @@ def test_query_slots_own_their_communicators(world, b, nslots):
     # the only constructions without a group are the one-off probes that pick the collective kind before the warm-up
     assert all(any(isinstance(t, ast.Name) and t.id == "probe" for p_ in ast.walk(tree) if isinstance(p_, ast.Assign) and p_.value is c
                    for t in p_.targets) for c in probes)
+
+
+def test_cpp_sharded_server_set_up_protocol_without_a_gpu(tmp_path):
+    """host/ShardedBatchedFHEPSIServer.hpp's session set-up over its side sockets, executed on the CPU box (the worker
+    side of the protocol had never run).  Rank 0 of two (tests/sharded_server_main.cpp) receives context, public key and EvalMult
+    key from this process playing the client, and must forward unique id, context, table secrets and key to its worker -- this
+    process again, reading the side socket -- with the channel's framing; a worker process receives the same four messages from
+    this process playing rank 0.  Both then reach the first call that needs a device and end there with the library's 'no HIP
+    device' error (the product has no CPU path): everything before it is host logic.  The unique id comes from the test-only RCCL
+    stand-in (tests/fake_rccl), preloaded so that the 0.5 GB library is not mapped for 128 random bytes.  Malformed set-up
+    messages are refused by size.  With a GPU present the same processes are run to completion by tests/test_rccl_ranks.py."""
+    import socket
+    import struct
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: tests/test_rccl_ranks.py runs the whole protocol")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "nested_hashing_psi_amd")
+    fake = str(tmp_path / "librccl.so.1")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", fake,
+                           os.path.join(root, "tests", "fake_rccl", "fake_rccl.cpp"), "-Wl,-soname,librccl.so.1", "-L/opt/rocm/lib",
+                           "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-lpthread"])
+    exe = str(tmp_path / "sharded_server_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(root, "tests", "sharded_server_main.cpp"), "-L" + libdir,
+                           "-lpiehip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    env = dict(os.environ, LD_PRELOAD=fake, PIEHIP_TEST_SEEDS="11,22,33")
+    setfile = tmp_path / "set.bin"
+    np.arange(1, 500, dtype=np.uint64).tofile(setfile)
+    tail = [str(setfile), "3", "40", "2", "8", "7"]
+    N, L, t = 4096, 2, 65537
+    from nested_hashing_psi_amd import pie
+    q, p = pie.default_moduli(N, L)
+    moduli = np.zeros(15, dtype=np.uint64)
+    moduli[:L], moduli[L:2 * L + 1] = q, p
+    ctx = struct.pack("IIQ", N, L, t) + moduli.tobytes()
+    rng = np.random.default_rng(1)
+    evk = rng.integers(0, int(q[-1]), (L, 2, L, N), dtype=np.uint64)
+
+    def send(s, payload):
+        s.sendall(struct.pack("i", len(payload)) + payload)
+
+    def recv(s):
+        hdr = b""
+        while len(hdr) < 4:
+            c = s.recv(4 - len(hdr))
+            assert c, "channel closed"
+            hdr += c
+        n, = struct.unpack("i", hdr)
+        buf = bytearray()
+        while len(buf) < n:
+            c = s.recv(min(1 << 20, n - len(buf)))
+            assert c, "channel closed"
+            buf += c
+        return bytes(buf)
+
+    # ---- rank 0: the client's messages in, four set-up messages out to the worker
+    client, c_srv = socket.socketpair()
+    side, s_srv = socket.socketpair()
+    proc = subprocess.Popen([exe, "0", "2", "0", str(c_srv.fileno()), str(s_srv.fileno())] + tail, pass_fds=(c_srv.fileno(), s_srv.fileno()),
+                            env=env, stderr=subprocess.PIPE)
+    c_srv.close()
+    s_srv.close()
+    send(client, ctx)
+    send(client, b"")
+    send(client, evk.tobytes())
+    uid = recv(side)
+    assert len(uid) == 128 and any(uid[:16]) and not any(uid[16:])     # the stand-in's id: 16 random bytes
+    assert recv(side) == ctx
+    assert recv(side) == struct.pack("QQQ", 11, 22, 33)                # evict, shuffle, mask: the same table on every rank
+    assert recv(side) == evk.tobytes()
+    _, err = proc.communicate(timeout=60)
+    assert proc.returncode == 1 and b"no HIP device" in err, err
+    client.close()
+    side.close()
+    # ---- a worker: the same four messages in
+    for bad in (None, "id", "seeds", "key"):
+        side, s_srv = socket.socketpair()
+        proc = subprocess.Popen([exe, "1", "2", "0", "-1", str(s_srv.fileno())] + tail, pass_fds=(s_srv.fileno(),), env=env, stderr=subprocess.PIPE)
+        s_srv.close()
+        try:
+            send(side, uid[:-1] if bad == "id" else uid)
+            send(side, ctx)
+            send(side, struct.pack("QQ", 1, 2) if bad == "seeds" else struct.pack("QQQ", 11, 22, 33))
+            send(side, evk.tobytes()[8:] if bad == "key" else evk.tobytes())
+        except (BrokenPipeError, ConnectionResetError):
+            assert bad is not None      # the worker hung up on a malformed message
+        _, err = proc.communicate(timeout=60)
+        assert proc.returncode == 1
+        want = {None: b"no HIP device", "id": b"unique id message size", "seeds": b"seed message size", "key": b"EvalMult key message size"}[bad]
+        assert want in err, (bad, err)
+        side.close()
