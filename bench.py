@@ -455,15 +455,17 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
         cnt = sum(a_[2] - b_[2] for a_, b_ in zip(after, before))
         return {"ms_per_query": tot / nqueries, "waits": cnt, "ms_per_wait": (tot / cnt if cnt else 0.0)}
 
-    # Every pass of a stream leg is instrumented: three events per run() on the handle's stream (piehip_set_host_path_timing) give the
-    # device-side time of its uploads (first staged piece -> last upload done) and of the rest (evaluation + the result list's way
-    # down); the host's wait for each run()'s results and for its turn on the link are recorded beside them.  A leg is one warm-up
+    # Every pass of a stream leg is instrumented: three events per run() stamped by the DEVICE in stream order
+    # (piehip_set_host_path_timing) give the time of its uploads (first staged piece -> last upload done) and of the rest (evaluation
+    # + the result list's way down); the host's time to issue each run(), its wait for that run()'s results and its wait for its
+    # turn on the link are recorded beside them, medians and maxima -- one stall names its side.  A leg is one warm-up
     # pass and TWO timed passes; the leg's figure is the faster timed pass, and all three passes are in the JSON line
     # (`stream_passes`) -- a pass that ran far from the link bound then shows which side was slow.  (r04: one leg of four sat at
     # 1.5-2.7 ms per query in some processes.  r05's passes show it is TRANSIENT -- the pass behind the slow one runs at the bound --
     # and that the host is not waiting for its turn during it: DESIGN.md section 4.)
     stream_passes = {"run_host_async_stream": {}, "staged_batch_stream": {}}
     collect = [None]
+    issue_ms = {}
 
     def run_leg(ops_, one_pass, nqueries, queries_per_run):
         for o_ in ops_:
@@ -480,7 +482,9 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
             med_ = lambda k_: sorted(g_[k_] for g_ in got)[len(got) // 2]
             passes_.append({"ms_per_query": wall * 1e3 / nqueries, "upload_ms_per_run": med_(0), "evaluate_and_download_ms_per_run": med_(1),
                             "upload_ms_per_run_max": max(g_[0] for g_ in got), "evaluate_and_download_ms_per_run_max": max(g_[1] for g_ in got),
-                            "host_wait_for_results_ms_per_run": med_(2), "upload_turn_wait": turn_wait_delta(ops_, w0_, nqueries),
+                            "host_wait_for_results_ms_per_run": med_(2), "host_wait_for_results_ms_per_run_max": max(g_[2] for g_ in got),
+                            "host_issue_ms_per_run": med_(3), "host_issue_ms_per_run_max": max(g_[3] for g_ in got),
+                            "upload_turn_wait": turn_wait_delta(ops_, w0_, nqueries),
                             "queries_per_run": queries_per_run})
         for o_ in ops_:
             o_.cc.set_host_path_timing(False)
@@ -507,9 +511,11 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
                         t_w = time.perf_counter()
                         o.waitHost()           # results of this slot's previous query are in host memory
                         if collect[0] is not None:
-                            collect[0].append(o.cc.host_path_times() + ((time.perf_counter() - t_w) * 1e3,))
+                            collect[0].append(o.cc.host_path_times() + ((time.perf_counter() - t_w) * 1e3, issue_ms.pop(id(o), 0.0)))
                     if i < nq:
+                        t_i = time.perf_counter()
                         o.runHostAsync(bi, bm, br)
+                        issue_ms[id(o)] = (time.perf_counter() - t_i) * 1e3
 
             pipelined[nslots], stream_passes["run_host_async_stream"][str(nslots)] = run_leg(allops, stream_queries, nq, 1)
     # The same stream with BATCHES of queries (the default timed region's mode, reached through the host-memory boundary the
@@ -542,14 +548,16 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
                         t_w = time.perf_counter()
                         o.waitHost()
                         if collect[0] is not None:
-                            collect[0].append(o.cc.host_path_times() + ((time.perf_counter() - t_w) * 1e3,))
+                            collect[0].append(o.cc.host_path_times() + ((time.perf_counter() - t_w) * 1e3, issue_ms.pop(id(o), 0.0)))
                     if i < nbatches:
+                        t_i = time.perf_counter()
                         for q_ in range(batch):
                             o.stageMinus(qb[q_][1], query=q_)
                         for h_ in range(K_):
                             for q_ in range(batch):
                                 o.stageIndexRow(h_, qb[q_][0][h_], query=q_)
                         o.runStaged(qb[0][2])
+                        issue_ms[id(o)] = (time.perf_counter() - t_i) * 1e3
 
             batched[nslots], stream_passes["staged_batch_stream"][str(nslots)] = run_leg(allops, stream_batches, nbatches * batch, batch)
             for o in allops:

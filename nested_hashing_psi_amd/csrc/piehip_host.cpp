@@ -332,6 +332,12 @@ int piehip_run_staged(piehip_handle h, uint64_t *results)
     h->host_results = results;
     rc = piehip_run_into(h, h->d_out);
     h->host_results = nullptr;
+    if (!rc && h->hp_timing && h->hp_ev_state == 2) {
+        // the third event goes into the stream NOW (behind the join with the run's queues), not when the host comes back to wait:
+        // what it stamps is then the device's time alone -- a host thread that is late does not show up in it
+        join_pending(h);
+        if (hipEventRecord(h->hp_ev[2], h->stream) == hipSuccess) h->hp_ev_state = 3;
+    }
     return rc;
 }
 
@@ -358,14 +364,14 @@ int piehip_run_host_wait(piehip_handle h)
     if (!h) return fail(PIEHIP_EINVAL, "null handle");
     HIPCHK(hipSetDevice(h->device));
     join_pending(h);  // uploads, evaluation and downloads are all behind the handle's stream now
-    if (h->hp_timing && h->hp_ev_state == 2 && hipEventRecord(h->hp_ev[2], h->stream) == hipSuccess) h->hp_ev_state = 3;
     HIPCHK(hipStreamSynchronize(h->stream));
     return PIEHIP_OK;
 }
 
 // Where a host-memory query spends its time ON THE DEVICE SIDE: events on the handle's stream at the first staged piece, behind the
 // last upload (piehip_run_staged) and behind the last download (piehip_run_host_wait).  upload_ms is the time the query's pieces
-// took to cross PCIe (from the moment the stream reached the first one), rest_ms the evaluation plus the result list's way down.
+// took to cross PCIe (from the moment the stream reached the first one), rest_ms the evaluation plus the result list's way down --
+// all three stamped by the device in stream order, independent of when the host calls what.
 int piehip_set_host_path_timing(piehip_handle h, int on)
 {
     NEED_RO(h);
