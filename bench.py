@@ -407,7 +407,7 @@ def projected_strong_scaling(torch, pie, cfg, device, local_rank, gen, steps, wa
     return out
 
 
-def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_streams=0, batch=1):
+def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_streams=0, batch=1, keep_gc=False):
     """The reference's own timer placement (BatchedFHEPSIServer.cpp:98-106): setMinusCompareElement + setIndex + run, with the
     query in HOST memory as the deserialised ciphertexts are -- so these figures include the PCIe upload that `value` leaves
     out.  Three ways across the boundary, medians of `iters` queries each:
@@ -416,6 +416,14 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
                        from pageable arrays and from the library's page-locked staging arrays (what a deserialiser would fill)"""
     idx_h = idx.cpu().numpy().view(np.uint64)
     minus_h = minus.cpu().numpy().view(np.uint64)
+    # CPython's cyclic garbage collector is switched off inside these legs (a full collection of a process that has torch and numpy
+    # loaded takes ~40 ms, and it fires -- deterministically, by allocation count -- inside one piehip_run_host_async call of the
+    # first stream leg: that one pause was r04's "slow leg", see DESIGN.md section 4; --keep-gc leaves the collector alone)
+    import gc
+    gc_was_on = gc.isenabled() and not keep_gc
+    if gc_was_on:
+        gc.collect()
+        gc.disable()
 
     def med(f, n):
         ts = []
@@ -568,6 +576,8 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
     for o_, i_, m_ in more_ops:
         o_.setIndexDevice(i_.data_ptr())
         o_.setMinusCompareElementDevice(m_.data_ptr())
+    if gc_was_on:
+        gc.enable()
     mib = (idx_h.nbytes + minus_h.nbytes) / 2**20
     out = {}
     if pipelined:
@@ -578,7 +588,7 @@ def reference_timer(torch, op, idx, minus, b, iters, device, more_ops=(), run_st
         best = min(batched, key=batched.get)
         out.update({"staged_batch_stream_ms_per_query": {str(n_): v_ * 1e3 for n_, v_ in batched.items()}, "staged_batch_queries_per_run": batch,
                     "staged_batch_slots": best, "value_staged_batch_stream": b / batched[best]})
-    return {**out, "unit": "ms", "iters": iters, "stream_passes": stream_passes,
+    return {**out, "unit": "ms", "iters": iters, "stream_passes": stream_passes, "python_gc_during_legs": bool(keep_gc),
             "stream_figure": "the faster of two timed passes per leg (after a warm-up pass); every pass is listed in stream_passes",
             "separate_calls_ms": sep * 1e3, "separate_calls_with_results_ms": sep_res * 1e3,
             "run_host_pageable_with_results_ms": host_pageable * 1e3, "run_host_pinned_with_results_ms": host_pinned * 1e3,
@@ -602,6 +612,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end PSI wall-clock leg")
     ap.add_argument("--no-projection", action="store_true", help="skip the projected strong-scaling legs")
+    ap.add_argument("--keep-gc", action="store_true", help="leave CPython's cyclic garbage collector on during the host-memory legs")
     ap.add_argument("--transform-slots", type=int, default=None,
                     help="cap on the persistent transform grids (workgroups); default: every slot on one GPU, 32 fewer (16 CUs left to RCCL) for N > 1")
     ap.add_argument("--no-ref-timer", action="store_true", help="skip the host-inputs (reference timer placement) leg")
@@ -1018,7 +1029,7 @@ def main():
             if len(slots) > 1:
                 cc.set_run_streams(args.streams or 1)   # the pipelined leg keeps every slot on one queue per run()
             rt = reference_timer(torch, op, idx, minus, b_local, 15, device, [(s_[1], s_[3], s_[4]) for s_ in slots[1:]], run_streams,
-                                 batch=DEFAULT_BATCH)
+                                 batch=DEFAULT_BATCH, keep_gc=args.keep_gc)
             cc.set_run_streams(run_streams)
             line["ref_timer"] = rt
             # reference timer placement, query in host memory, result list back in host memory when the timer stops: one query
