@@ -886,6 +886,13 @@ def main():
     # The timed region.  N = 1: the queries are resident in HBM when a step starts.  N > 1: they are resident in RANK 0's HBM (the
     # rank that holds the client's socket, BatchedFHEPSIServer.cpp:94-99) and every step distributes its queries to all ranks -- the
     # line's `value`; the steps are first timed with the queries already on every rank (`queries_resident_on_every_rank`).
+    # (CPython's cyclic garbage collector stays off from here to the end of the measurements: a full collection of this process takes
+    # ~40 ms -- 65 steps of the timed region -- and fires by allocation count wherever the Python harness happens to be;
+    # profiles/r05/host_stream_slow_leg_is_python_gc.txt.  The product is the C library; --keep-gc leaves the collector alone.)
+    if not args.keep_gc:
+        import gc
+        gc.collect()
+        gc.disable()
     blocks = run_blocks()
     ms_per_step = median(blocks)
     dist_blocks = None
@@ -973,6 +980,7 @@ def main():
             "timing": "median of %d blocks of exactly %d steps, each bracketed by barrier + synchronize, after >= %d steps and >= %.2f s "
                       "of warm-up" % (len(blocks), args.steps, args.warmup, args.warm_seconds),
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "python_gc": "left on (--keep-gc)" if args.keep_gc else "off during the measurements (a harness pause, not the product's: see bench.py)",
             "config": {"workload": "%s: BatchedFHEHIPPIE::run(), N=%d, %d RNS primes (60-bit), t=%d, |S|=2^%d |C|=2^%d, k=%d e=%d (B=%d slots), "
                                    "K=%d E=%d, b=%d bin layers in all, %d on rank 0; %d quer%s per step: %d ct x pt MACs + %d ct x ct (HPS + BV relin) + %d mask mults per step"
                                    % (cname, N, L, t, cfg["S"].bit_length() - 1, cfg["C"].bit_length() - 1, cfg["k"], cfg["e"], B, K, E,
