@@ -610,6 +610,63 @@ def test_query_slots_on_one_database(ob, pie, N, L, K, E, b, depth):
     cc.close()
 
 
+def test_staged_queries_from_several_host_threads(ob, pie):
+    """One host thread per handle, as the C ABI allows (SURVEY 8b "Threading"): three query slots on one database, each driven by a
+    thread of its own that stages queries piece by piece from page-locked memory and waits for the result lists, all at once.  The
+    threads meet in the library's per-device upload order (piehip_host.cpp DeviceUploads: one staging sequence at a time takes the
+    link, the others queue up behind it -- r05 replaced a process-wide mutex that was held while polling); every query of every
+    thread equals the oracle's run(), the turn waits are recorded, nothing deadlocks."""
+    import threading
+    import torch
+    N, L, t, K, E, b, depth, rounds = 8192, 3, T32, 2, 4, 6, 3, 6
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(31337)
+    db, masks, evk = rand_limbs(rng, cc.q, (K, b, E), N), rand_limbs(rng, cc.q, (b,), N), rand_limbs(rng, cc.q, (L, 2), N)
+    cc.load_relin_key(evk)
+    op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+    streams = [torch.cuda.Stream() for _ in range(depth - 1)]
+    it = iter(streams)
+    pipe = pie.QueryPipeline(op, depth, lambda: pie.PieContext(N, L, t, stream=next(it).cuda_stream))
+    queries = [[(rand_limbs(rng, cc.q, (K, E, 2), N), rand_limbs(rng, cc.q, (2,), N)) for _ in range(rounds)] for _ in range(depth)]
+    want = [[o.pie_run(idx, minus, db, masks, evk) for idx, minus in qs] for qs in queries]
+    bufs = [s.hostBuffers() for s in pipe.slots]
+    errors = []
+    start = threading.Barrier(depth)
+
+    def drive(i):
+        try:
+            s, (pi, pm, pr) = pipe.slots[i], bufs[i]
+            start.wait()
+            for r, (idx, minus) in enumerate(queries[i]):
+                pi[...] = idx
+                pm[...] = minus
+                pr[...] = 0
+                s.stageMinus(pm)
+                for h in range(K):
+                    for j in range(E):
+                        s.stageIndexCiphertext(h, j, pi[h, j])
+                s.runStaged(pr)
+                s.waitHost()
+                if not (pr == want[i][r]).all():
+                    errors.append("thread %d, query %d differs from the oracle" % (i, r))
+        except Exception as exc:   # noqa: BLE001 -- reported by the main thread
+            errors.append("thread %d: %r" % (i, exc))
+
+    threads = [threading.Thread(target=drive, args=(i,)) for i in range(depth)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not any(th.is_alive() for th in threads), "a staging thread is stuck"
+    assert not errors, errors
+    waits = [s.cc.upload_turn_wait() for s in pipe.slots]
+    assert sum(w[2] for w in waits) > 0          # the threads did queue up behind each other's uploads ...
+    assert max(w[0] for w in waits) < 1000.0     # ... for as long as an upload takes, not for the 5 s bound
+    pipe.close()
+    cc.close()
+
+
 @pytest.mark.parametrize("N,L,K,E,b", [(4096, 2, 2, 5, 5), (16384, 4, 2, 3, 4), (8192, 3, 3, 4, 3)])
 def test_run_host_pipelined_call_matches_separate_calls(ob, pie, N, L, K, E, b):
     """piehip_run_host (row-wise upload under stage A, per-group download) == setMinusCompareElement + setIndex + run +
