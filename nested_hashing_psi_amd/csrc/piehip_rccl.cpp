@@ -201,20 +201,28 @@ int piehip_rccl_wait(piehip_handle h, uint32_t timeout_ms)
     if (!R) return no_rccl();
     const auto t0 = std::chrono::steady_clock::now();
     std::string why;
-    for (;;) {
+    // The common case is a query's worth of work (well under a millisecond at the headline shape): the stream is polled back to back
+    // for the first milliseconds -- this wait sits inside the server's online timer -- and the communicator's error state and the
+    // clock are looked at every 64th poll; after 5 ms the loop backs off to one poll per 50 us.
+    for (u32 polls = 0;; polls++) {
         const hipError_t q = hipStreamQuery(h->stream);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) return fail(PIEHIP_EHIP, std::string("rccl_wait: ") + hipGetErrorString(q));
+        if ((polls & 63) != 63) {
+            std::this_thread::yield();
+            continue;
+        }
         ncclResult_t ae = ncclSuccess;
         if (R->CommGetAsyncError && R->CommGetAsyncError((ncclComm_t)h->comm, &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress) {
             why = std::string("rccl_wait: the communicator reports ") + R->GetErrorString(ae);
             break;
         }
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) {
+        const auto waited = std::chrono::steady_clock::now() - t0;
+        if (waited > std::chrono::milliseconds(timeout_ms)) {
             why = "rccl_wait: timed out after " + std::to_string(timeout_ms) + " ms -- a rank of the server group did not join the collective";
             break;
         }
-        std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (waited > std::chrono::milliseconds(5)) std::this_thread::sleep_for(std::chrono::microseconds(50) * 64);
     }
     if (why.empty()) {
         // (the stream has drained; a transfer that FAILED also drains it: ask once more)
