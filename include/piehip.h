@@ -41,6 +41,9 @@ extern "C" {
 
 typedef struct piehip_ctx *piehip_handle;
 
+/* 100 = rounds 1-4; 101 (round 5) adds piehip_profile_read_n, piehip_set/get_transform_slots, piehip_upload_turn_wait,
+ * piehip_set_host_path_timing / piehip_host_path_times, piehip_rccl_wait / _abort / _agree; nothing of 100 changed its signature or
+ * its meaning (piehip_profile_read keeps writing the twelve kernel classes of version 100). */
 int piehip_version(void);
 const char *piehip_last_error(void);
 
