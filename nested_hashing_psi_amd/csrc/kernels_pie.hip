@@ -905,7 +905,7 @@ __device__ __forceinline__ void scale_pq_core(const DevConsts *dc, const u64 (&x
         u64 col[L];
 #pragma unroll
         for (u32 i = 0; i < L; i++) col[i] = c->PI_modp[i][j];
-        const u64 w = c->phat_inv[j], wsh = c->phat_inv_sh[j], nq = neg_u(pj.q), n2q = neg_u(2 * pj.q);
+        const u64 w = c->phat_inv[j], wsh = c->phat_inv_sh[j], nq = neg_u(pj.q);
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             u64 r;
@@ -1156,7 +1156,7 @@ __device__ __forceinline__ void scale_round_core(const DevConsts *dc, const u64 
         u64 col[Lp];
 #pragma unroll
         for (u32 j = 0; j < Lp; j++) col[j] = c->tQF_modq[j][k];
-        const u64 tp = c->tPinv_modq[k], nq = neg_u(qk.q), n2q = neg_u(2 * qk.q);
+        const u64 tp = c->tPinv_modq[k], nq = neg_u(qk.q);
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             if (MAD && L <= 6) {   // L + 2 products + the integer parts (< (L + 2) 2^60, in column 0)
