@@ -289,6 +289,7 @@ int piehip_gather_results_host(piehip_handle h, uint32_t b_total, int root, uint
  *   piehip_rccl_wait    piehip_sync with a time-out (milliseconds): polls the handle's stream and the communicator's asynchronous
  *                       error state; when the time is up or RCCL reports a failed peer it aborts the communicator (ncclCommAbort
  *                       releases the blocked stream) and returns PIEHIP_EHIP -- the handle has no communicator afterwards
+ *                       (a communicator given with piehip_rccl_attach is only dropped: aborting it is its owner's business)
  *   piehip_rccl_abort   the same on purpose: a rank on its way out tears its side down, its peers' waits end at once
  *   piehip_rccl_agree   *all_ok = (every rank passed ok != 0): one all-reduced word + piehip_rccl_wait; called at the end of a phase
  *                       (database built, key loaded) so that a failure on one rank ends the session on all of them BEFORE anybody

@@ -232,7 +232,10 @@ int piehip_rccl_wait(piehip_handle h, uint32_t timeout_ms)
         else
             return PIEHIP_OK;
     }
+    const bool owned = h->comm_owned;
     abort_comm(h, R);
+    if (!owned)   // piehip_rccl_attach: the communicator is the caller's to abort -- until then the stream may still be blocked
+        return fail(PIEHIP_EHIP, why + " (attached communicator dropped: the caller must ncclCommAbort it to release the stream)");
     (void)hipStreamSynchronize(h->stream);   // the abort released whatever of the collective sat in the stream
     return fail(PIEHIP_EHIP, why + " (communicator aborted)");
 }
