@@ -244,10 +244,14 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_batch_kernel(const DevConsts 
                                                                 u32 bstride, u32 h0, u32 nq, u32 q0, u32 tiles, StageAXOut xo)
 {
     StageATile tl;
-    if (!stage_a_tile((N + TPB - 1) / TPB, L, tiles, b / BPT, tl)) return;
+    if (!stage_a_tile((N + TPB - 1) / TPB, L, tiles, (b + BPT - 1) / BPT, tl)) return;
     const u32 nl = threadIdx.x, n0 = tl.bx * TPB, l = tl.l, h = h0 + tl.hz, beta0 = tl.grp * BPT;
     const u32 n = n0 + nl;
     if (n >= N) return;
+    // the last group of a launch may hold fewer than BPT layers (b no multiple of BPT): its missing layers repeat its last one --
+    // the same loads again (L1 hits) and multiply-adds nobody stores -- so that the term loop stays free of per-layer branches
+    // (skipping them under uniform branches instead was measured: 4-17 % slower, profiles/r05/stage_a_batch_layer_groups.txt)
+    const u32 tmax = __builtin_amdgcn_readfirstlane(min((u32)BPT, b - beta0) - 1);
     const Mod m = dc->mod[l];
     const size_t LN = (size_t)L * N;
     const size_t ioff = ((size_t)h * E) * 2 * LN + (size_t)l * N + n0;
@@ -267,7 +271,7 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_batch_kernel(const DevConsts 
         }
         const u64 *pdj = pd + (size_t)j * LN;
 #pragma unroll
-        for (int t = 0; t < BPT; t++) vd[t] = __builtin_nontemporal_load(pdj + (size_t)t * bin_stride + nl);
+        for (int t = 0; t < BPT; t++) vd[t] = __builtin_nontemporal_load(pdj + (size_t)min((u32)t, tmax) * bin_stride + nl);
     };
     u64 qiv[DEPTH][Q][2], qdv[DEPTH][BPT];
 #pragma unroll
@@ -313,6 +317,7 @@ __global__ void __launch_bounds__(TPB) stage_a_mad_batch_kernel(const DevConsts 
         for (int c = 0; c < 2; c++) mi[c] = qs.minus[q][(size_t)c * LN + (size_t)l * N + n];
 #pragma unroll
         for (int t = 0; t < BPT; t++) {
+            if ((u32)t > tmax) continue;   // (uniform: a layer the ragged last group does not have)
             const size_t row = (size_t)(beta0 + t) * nq + q0 + q;
             // operand X of the first product goes straight to the QP operand array, lane-ordered (StageAXOut).  Uniform choices
             // of base and stride, and the lane offset blended with a mask: no per-lane selects (v_cndmask on VCC: see addmod_nb)
@@ -393,37 +398,36 @@ static void launch_stage_a_batch_qb(const DevConsts *dc, u32 N, u32 L, u32 K, u3
                                     u64 *acc, hipStream_t st, u32 bstride, u32 h0, u32 hn, u32 nq, u32 q0, StageAXOut xo)
 {
     const u32 nx = (N + TPB - 1) / TPB;
-    constexpr int DEPTH = Q == 4 ? 2 : 3;  // terms in flight behind the one being accumulated (profiles/r03/stage_a_batch_microbench.txt)
-    hipLaunchKernelGGL((stage_a_mad_batch_kernel<BPT, Q, DEPTH>), stage_a_grid(nx, L, hn, nb / BPT), dim3(TPB), 0, st, dc, N, L, K, nb, E,
-                       qs, db, acc, bstride, h0, nq, q0, nx * L * hn, xo);
+    // terms in flight behind the one being accumulated (profiles/r03/stage_a_batch_microbench.txt; r05: two for the wide tilings)
+    constexpr int DEPTH = (Q == 4 || Q * BPT >= 9) ? 2 : 3;
+    hipLaunchKernelGGL((stage_a_mad_batch_kernel<BPT, Q, DEPTH>), stage_a_grid(nx, L, hn, (nb + BPT - 1) / BPT), dim3(TPB), 0, st, dc, N, L, K,
+                       nb, E, qs, db, acc, bstride, h0, nq, q0, nx * L * hn, xo);
 }
+// Bin layers per thread.  What bounds this kernel is the traffic through the L1s (profiles/r05/stage_a_batch_prefetch_really_in_flight.txt:
+// ~8.6 TB/s of L1 misses chip-wide, three quarters of them index words that a thread re-reads from the L2 once per GROUP of layers), so
+// groups should be as large as the registers allow while three waves still fit a SIMD: four layers for two queries, three for three
+// queries (164 VGPRs either way), two for four.  r03-r04 had two layers for three queries: 81.7 us for twelve layers against 69.9 with
+// groups of three (tools/microbench_stage_a_batch.hip, r05).  ONE launch whatever the layer count: the last group is ragged (the
+// kernel repeats its last layer) -- a remainder launch of one or two layers is all latency (25 us for two layers alone), and two
+// launches of half the groups each leave the chip a partial round of waves twice.
 template <int Q>
 static void launch_stage_a_batch_q(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const StageAQueries &qs, const u64 *db,
                                    u64 *acc, hipStream_t st, u32 bstride, u32 h0, u32 hn, u32 nq, u32 q0, StageAXOut xo)
 {
-    constexpr u32 cap = Q == 2 ? 4 : 2;  // bin layers per thread: Q * cap accumulator pairs (eight at most)
-    const size_t LN = (size_t)L * N;
-    auto go = [&](u32 nb, u32 bpt, const u64 *dbp, u64 *accp, StageAXOut x) {
-        if constexpr (cap >= 4) {
-            if (bpt == 4) return launch_stage_a_batch_qb<Q, 4>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0, x);
-            if (bpt == 3) return launch_stage_a_batch_qb<Q, 3>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0, x);
-        }
-        if (bpt == 2) return launch_stage_a_batch_qb<Q, 2>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0, x);
-        return launch_stage_a_batch_qb<Q, 1>(dc, N, L, K, nb, E, qs, dbp, accp, st, bstride, h0, hn, nq, q0, x);
-    };
-    u32 bpt = 0;
-    for (u32 c = cap; c >= 2; c--)
-        if (b % c == 0) {
-            bpt = c;
-            break;
-        }
-    if (b <= cap) bpt = b;
-    if (bpt) return go(b, bpt, db, acc, xo);
-    const u32 full = (b / cap) * cap, rest = b - full;
-    go(full, cap, db, acc, xo);
-    StageAXOut xr = xo;
-    if (xr.out) xr.out += (size_t)full * nq * 4 * xr.M * N;
-    go(rest, rest, db + (size_t)full * E * LN, acc + (size_t)full * nq * K * 2 * LN, xr);
+    constexpr u32 cap = Q == 2 ? 4 : (Q == 3 ? 3 : 2);  // bin layers per thread
+    // the group size that issues the fewest loads per term over the launch: ceil(b / g) groups of 2 Q index words + g database words
+    // (a ragged last group loads and multiplies its padding too: six layers of two queries are better off as 3 + 3 than as 4 + 2)
+    u32 bpt = 1, best = ~0u;
+    for (u32 g = 1; g <= cap && g <= b; g++) {
+        const u32 loads = ((b + g - 1) / g) * (2 * Q + g);
+        if (loads <= best) best = loads, bpt = g;
+    }
+    if constexpr (cap >= 4)
+        if (bpt == 4) return launch_stage_a_batch_qb<Q, 4>(dc, N, L, K, b, E, qs, db, acc, st, bstride, h0, hn, nq, q0, xo);
+    if constexpr (cap >= 3)
+        if (bpt == 3) return launch_stage_a_batch_qb<Q, 3>(dc, N, L, K, b, E, qs, db, acc, st, bstride, h0, hn, nq, q0, xo);
+    if (bpt == 2) return launch_stage_a_batch_qb<Q, 2>(dc, N, L, K, b, E, qs, db, acc, st, bstride, h0, hn, nq, q0, xo);
+    return launch_stage_a_batch_qb<Q, 1>(dc, N, L, K, b, E, qs, db, acc, st, bstride, h0, hn, nq, q0, xo);
 }
 void launch_stage_a_batch(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const StageAQueries &qs, u32 nq, const u64 *db,
                           u64 *acc, hipStream_t st, bool small_moduli, u32 bstride, u32 h0, u32 hn, const StageAXOut *xop)

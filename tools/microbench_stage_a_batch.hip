@@ -15,12 +15,12 @@ static u64 *g_idx[8], *g_minus, *g_db, *g_acc;
 static DevConsts *g_dc;
 
 template <int BPT, int Q, int DEPTH>
-static void run(bool same_idx)
+static void run(bool same_idx, u32 Bl = B)   // Bl: bin layers of this launch (<= B; the last group may be ragged)
 {
     StageAQueries qs = {};
     for (int q = 0; q < Q; q++) qs.idx[q] = g_idx[same_idx ? 0 : q], qs.minus[q] = g_minus;
     const u32 nx = N / TPB, tiles = nx * L * K;
-    const dim3 grid = stage_a_grid(nx, L, K, B / BPT);
+    const dim3 grid = stage_a_grid(nx, L, K, (Bl + BPT - 1) / BPT);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float sum = 0;
@@ -35,8 +35,8 @@ static void run(bool same_idx)
         if (rep) sum += ms;
     }
     const float avg = sum / (NREP - 1) * 1e3f;
-    const double bytes = 8.0 * L * N * ((double)K * B * E + Q * ((double)K * E * 2 + 2 + (double)B * K * 2));
-    printf("Q=%d BPT=%d depth=%d %s: %7.1f us per launch, %6.1f us per query, compulsory %.0f MiB -> %.2f TB/s\n", Q, BPT, DEPTH,
+    const double bytes = 8.0 * L * N * ((double)K * Bl * E + Q * ((double)K * E * 2 + 2 + (double)Bl * K * 2));
+    printf("layers=%u Q=%d BPT=%d depth=%d %s: %7.1f us per launch, %6.1f us per query, compulsory %.0f MiB -> %.2f TB/s\n", Bl, Q, BPT, DEPTH,
            same_idx ? "same idx    " : "distinct idx", avg, avg / Q, bytes / 1048576.0, bytes / avg / 1e6);
 }
 int main()
@@ -56,10 +56,17 @@ int main()
     CK(hipMemset(g_db, 1, NBUF * dbw * 8)); CK(hipMemset(g_minus, 3, 2 * LN * 8));
     for (int q = 0; q < 8; q++) { CK(hipMalloc(&g_idx[q], idw * 8)); CK(hipMemset(g_idx[q], 2 + q, idw * 8)); }
     for (int s = 0; s < 2; s++) {
-        run<4, 2, 3>(s);
-        run<2, 3, 3>(s);
-        run<2, 3, 2>(s);
-        run<2, 4, 2>(s);
+        run<2, 3, 3>(s);          // r03-r04's tiling for three queries: seven groups of two layers
+        run<3, 3, 2>(s);          // r05: five groups of three, the last one ragged (shipped)
+        run<4, 3, 2>(s);          // four groups of four, the last one ragged (204 VGPRs: two waves per SIMD)
+        run<2, 3, 3>(s, 12);
+        run<3, 3, 2>(s, 12);
+        run<3, 3, 3>(s, 12);
+        run<4, 3, 2>(s, 12);
+        run<2, 3, 3>(s, 2);       // a remainder launch of two layers: all latency
+        run<4, 2, 3>(s);          // two queries: four groups of four, ragged (shipped)
+        run<4, 2, 3>(s, 12);
+        run<2, 4, 2>(s);          // four queries (shipped)
     }
     return 0;
 }
