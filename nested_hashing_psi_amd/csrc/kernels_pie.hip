@@ -405,8 +405,8 @@ static void launch_stage_a_batch_qb(const DevConsts *dc, u32 N, u32 L, u32 K, u3
 }
 // Bin layers per thread.  What bounds this kernel is the traffic through the L1s (profiles/r05/stage_a_batch_prefetch_really_in_flight.txt:
 // ~8.6 TB/s of L1 misses chip-wide, three quarters of them index words that a thread re-reads from the L2 once per GROUP of layers), so
-// groups should be as large as the registers allow while three waves still fit a SIMD: four layers for two queries, three for three
-// queries (164 VGPRs either way), two for four.  r03-r04 had two layers for three queries: 81.7 us for twelve layers against 69.9 with
+// groups should be as large as the registers allow: four layers for two queries, three for three queries (164 VGPRs either way:
+// three waves per SIMD), three for four (208: two waves).  r03-r04 had two layers for three queries: 81.7 us for twelve layers against 69.9 with
 // groups of three (tools/microbench_stage_a_batch.hip, r05).  ONE launch whatever the layer count: the last group is ragged (the
 // kernel repeats its last layer) -- a remainder launch of one or two layers is all latency (25 us for two layers alone), and two
 // launches of half the groups each leave the chip a partial round of waves twice.
@@ -414,7 +414,7 @@ template <int Q>
 static void launch_stage_a_batch_q(const DevConsts *dc, u32 N, u32 L, u32 K, u32 b, u32 E, const StageAQueries &qs, const u64 *db,
                                    u64 *acc, hipStream_t st, u32 bstride, u32 h0, u32 hn, u32 nq, u32 q0, StageAXOut xo)
 {
-    constexpr u32 cap = Q == 2 ? 4 : (Q == 3 ? 3 : 2);  // bin layers per thread
+    constexpr u32 cap = Q == 2 ? 4 : 3;  // bin layers per thread (Q = 4, three layers: 208 VGPRs, two waves -- still 4 % ahead of two layers)
     // the group size that issues the fewest loads per term over the launch: ceil(b / g) groups of 2 Q index words + g database words
     // (a ragged last group loads and multiplies its padding too: six layers of two queries are better off as 3 + 3 than as 4 + 2)
     u32 bpt = 1, best = ~0u;
