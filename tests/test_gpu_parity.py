@@ -925,6 +925,47 @@ def test_profile_read_lengths(ob, pie):
     cc.close()
 
 
+def test_batch_layer_groups_over_many_shapes(ob, pie):
+    """Stage A of a query batch picks its bin layers per thread by the layer count (groups of up to four / three layers for two / three
+    and four queries, one launch, the last group ragged: r05).  Every layer count 1 .. 17 with every batch size 2 .. 8 (i.e. every
+    split into launches of two, three and four queries), on both queue counts: each query's result list equals the result of running
+    that query ALONE (the single-query kernel, a different code path), and for a sample of the shapes the oracle's run()."""
+    N, L, t, K = 2048, 2, T32, 2
+    o = ob.Oracle(N, L, t)
+    cc = pie.PieContext(N, L, t)
+    rng = np.random.default_rng(20261005)
+    q = cc.q
+    evk = rand_limbs(rng, q, (L, 2), N)
+    cc.load_relin_key(evk)
+    for b in range(1, 18):
+        E = (5, 9, 17)[b % 3]     # no carry sweep / one carry sweep / a mid-sum reduction of the column accumulators
+        queries = [(rand_limbs(rng, q, (K, E, 2), N), rand_limbs(rng, q, (2,), N)) for _ in range(8)]
+        db, masks = rand_limbs(rng, q, (K, b, E), N), rand_limbs(rng, q, (b,), N)
+        op = pie.BatchedFHEHIPPIE(cc, vectorizedHCT=db, preCalcRandomMask=masks)
+        alone = []
+        for idx, minus in queries:
+            op.setMinusCompareElement(minus)
+            op.setIndex(idx)
+            op.run()
+            alone.append(op.getResultList().copy())
+        if b in (1, 5, 7, 14, 17):
+            for i in (0, 7):
+                assert (alone[i] == o.pie_run(queries[i][0], queries[i][1], db, masks, evk)).all(), "b = %d, query %d alone vs the oracle" % (b, i)
+        for nq in range(2, 9):
+            op.setQueryBatch(nq)
+            for i in range(nq):
+                op.setMinusCompareElement(queries[i][1], query=i)
+                op.setIndex(queries[i][0], query=i)
+            for streams in (1, 0):
+                cc.set_run_streams(streams)
+                op.run()
+                got = op.getResultList()
+                for i in range(nq):
+                    assert (got[i] == alone[i]).all(), "b = %d, batch of %d, query %d, %d queue(s)" % (b, nq, i, streams or 2)
+        op.setQueryBatch(1)
+    cc.close()
+
+
 @pytest.mark.parametrize("E,b", [(1, 1), (1, 3), (15, 2), (16, 3), (40, 5)])
 def test_run_shape_extremes(ob, pie, E, b):
     """one inner position, the last E of the carry-free accumulator (15), the first E of the 128-bit accumulator (16), a long
