@@ -1300,16 +1300,21 @@ void launch_digits(const DevConsts *dc, u32 N, u32 L, const u64 *d2, size_t stri
 // tau0 .. tau0 + 256 / KP - 1, i.e. KP contiguous runs of the lane order, and hands the results through LDS so that they leave
 // as one contiguous 4 KiB run of the standard order; with the plain out_map scatter every 16-byte store lands in its own
 // stretch.  KP = 16: kernels_ntt_fast.hip (32 coefficients per thread), KP = 8: ntt16_kernel.h.
-template <bool MAD, int KP>
+// RPT = 2 (column-accumulator path only): one thread takes the same coefficient pair of TWO ciphertext rows that use the same key -- rows
+// r and r + key_group -- and loads every key word once for both.  The kernel is bound by the traffic through the L1s (330 MB per step at
+// the headline shape, more than half of it key words that every row re-reads from the L2: profiles/r05/stage_a_batch_layer_groups.txt
+// has the model); a launch's last block of rows may have no second row (uniform branch).
+template <bool MAD, int KP, int RPT = 1>
 __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restrict__ dc, u32 N, u32 L, const u64 *__restrict__ d01,
                                                         size_t stride01, const u64 *__restrict__ dig,
                                                         const u64 *__restrict__ key0, const u64 *__restrict__ mask,
                                                         u64 *__restrict__ out, const u32 *__restrict__ out_map,
-                                                        size_t key_stride, u32 key_group, u32 T, u32 mask_div)
+                                                        size_t key_stride, u32 key_group, u32 T, u32 mask_div, u32 nb)
 {
+    static_assert(RPT == 1 || MAD, "two rows per thread: the column-accumulator path");
     constexpr bool TILE = KP > 0;
     constexpr u32 TT = TILE ? TPB / (KP ? KP : 1) : 1;  // threads of the transform per tile
-    __shared__ u64x2 s_tile[TILE ? 2 : 1][TILE ? TPB : 1];
+    __shared__ u64x2 s_tile[TILE ? 2 * RPT : 1][TILE ? TPB : 1];
     u32 n = 2 * (blockIdx.x * TPB + threadIdx.x);
     u32 std_pair = 0;  // TILE: first standard-order pair of this block's tile
     if (TILE) {
@@ -1319,45 +1324,72 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restr
         std_pair = slice * KP * T + KP * tau0;
     }
     if (n >= N) return;
-    const u32 j = blockIdx.y, bin = blockIdx.z;
+    const u32 j = blockIdx.y;
+    // rows of this thread: RPT = 1: row blockIdx.z; RPT = 2: rows 2 k G + q and (2 k + 1) G + q of key q (k = z / G, q = z % G)
+    u32 rows[RPT];
+    bool has[RPT];
+    if (RPT == 1) {
+        rows[0] = blockIdx.z, has[0] = true;
+    } else {
+        const u32 k = blockIdx.z / key_group, q = blockIdx.z % key_group;
+        rows[0] = 2 * k * key_group + q, has[0] = rows[0] < nb;
+        rows[RPT - 1] = rows[0] + key_group, has[RPT - 1] = rows[RPT - 1] < nb;
+        if (!has[0]) return;
+    }
+    const u32 bin = rows[0];
     const u64 *key = key0 + (size_t)(bin % key_group) * key_stride;  // one key per position in a group (EvalMerge)
     const Mod m = dc->mod[j];
     const size_t LN = (size_t)L * N;
-    u64x2 mk;
-    if (mask) mk = *reinterpret_cast<const u64x2 *>(mask + (size_t)(bin / mask_div) * LN + (size_t)j * N + n);
     const u32 po = TILE ? 0 : (out_map ? out_map[n] : n);
-    u64x2 res[2];
+    u64x2 res[RPT][2];
     if (MAD) {
         // column accumulators end to end: the L products, then d01 (it may arrive unnormalised, < 2^63, from the forward
         // transform) into column 0 -- (L + 8) 2^60 < 2^64 -- and one reduction block; the mask product likewise
-        ColAcc a[2][2] = {{{0, 0, 0}, {0, 0, 0}}, {{0, 0, 0}, {0, 0, 0}}};
+        ColAcc a[RPT][2][2];
+#pragma unroll
+        for (int r = 0; r < RPT; r++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) a[r][c][0] = a[r][c][1] = ColAcc{0, 0, 0};
         for (u32 i = 0; i < L; i++) {
-            const u64x2 d = *reinterpret_cast<const u64x2 *>(dig + (((size_t)bin * L + i) * L + j) * N + n);
             const u64x2 k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)i * 2 + 0) * L + j) * N + n);
             const u64x2 k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)i * 2 + 1) * L + j) * N + n);
-            const Split30 dx = split30(d.x), dy = split30(d.y);
-            colacc_mac(a[0][0], dx, split30(k0.x));
-            colacc_mac(a[0][1], dy, split30(k0.y));
-            colacc_mac(a[1][0], dx, split30(k1.x));
-            colacc_mac(a[1][1], dy, split30(k1.y));
+            const Split30 k0x = split30(k0.x), k0y = split30(k0.y), k1x = split30(k1.x), k1y = split30(k1.y);
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                if (r && !has[r]) continue;
+                const u64x2 d = *reinterpret_cast<const u64x2 *>(dig + (((size_t)rows[r] * L + i) * L + j) * N + n);
+                const Split30 dx = split30(d.x), dy = split30(d.y);
+                colacc_mac(a[r][0][0], dx, k0x);
+                colacc_mac(a[r][0][1], dy, k0y);
+                colacc_mac(a[r][1][0], dx, k1x);
+                colacc_mac(a[r][1][1], dy, k1y);
+            }
         }
         const u64 nq = 0 - m.q;
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const u64x2 s = *reinterpret_cast<const u64x2 *>(d01 + (size_t)bin * stride01 + (size_t)c * LN + (size_t)j * N + n);
-            a[c][0].c0 += s.x;
-            a[c][1].c0 += s.y;
-            res[c].x = colacc_reduce<false>(a[c][0], m, nq);
-            res[c].y = colacc_reduce<false>(a[c][1], m, nq);
-            if (mask) {
-                ColAcc p0 = {0, 0, 0}, p1 = {0, 0, 0};
-                colacc_mac(p0, split30(res[c].x), split30(mk.x));
-                colacc_mac(p1, split30(res[c].y), split30(mk.y));
-                res[c].x = colacc_reduce<false>(p0, m, nq);
-                res[c].y = colacc_reduce<false>(p1, m, nq);
+        for (int r = 0; r < RPT; r++) {
+            if (r && !has[r]) continue;
+            u64x2 mk;
+            if (mask) mk = *reinterpret_cast<const u64x2 *>(mask + (size_t)(rows[r] / mask_div) * LN + (size_t)j * N + n);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const u64x2 s = *reinterpret_cast<const u64x2 *>(d01 + (size_t)rows[r] * stride01 + (size_t)c * LN + (size_t)j * N + n);
+                a[r][c][0].c0 += s.x;
+                a[r][c][1].c0 += s.y;
+                res[r][c].x = colacc_reduce<false>(a[r][c][0], m, nq);
+                res[r][c].y = colacc_reduce<false>(a[r][c][1], m, nq);
+                if (mask) {
+                    ColAcc p0 = {0, 0, 0}, p1 = {0, 0, 0};
+                    colacc_mac(p0, split30(res[r][c].x), split30(mk.x));
+                    colacc_mac(p1, split30(res[r][c].y), split30(mk.y));
+                    res[r][c].x = colacc_reduce<false>(p0, m, nq);
+                    res[r][c].y = colacc_reduce<false>(p1, m, nq);
+                }
             }
         }
     } else {
+        u64x2 mk;
+        if (mask) mk = *reinterpret_cast<const u64x2 *>(mask + (size_t)(bin / mask_div) * LN + (size_t)j * N + n);
         U128 acc[2][2];
 #pragma unroll
         for (int c = 0; c < 2; c++)
@@ -1378,47 +1410,59 @@ __global__ void __launch_bounds__(TPB) relin_mac_kernel(const DevConsts *__restr
             // d01 joins the sum before the reduction: it may arrive unnormalised (< 2^63) from the forward transform
             add128(acc[c][0], U128{s.x, 0});
             add128(acc[c][1], U128{s.y, 0});
-            res[c].x = reduce128(acc[c][0], m);
-            res[c].y = reduce128(acc[c][1], m);
+            res[0][c].x = reduce128(acc[c][0], m);
+            res[0][c].y = reduce128(acc[c][1], m);
             if (mask) {
-                res[c].x = mulmod(res[c].x, mk.x, m);
-                res[c].y = mulmod(res[c].y, mk.y, m);
+                res[0][c].x = mulmod(res[0][c].x, mk.x, m);
+                res[0][c].y = mulmod(res[0][c].y, mk.y, m);
             }
         }
     }
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const u64x2 r = res[c];
-        if (TILE)
-            s_tile[c][KP * (threadIdx.x % TT) + threadIdx.x / TT] = r;  // standard offset inside the tile: KP (tau - tau0) + k
-        else
-            *reinterpret_cast<u64x2 *>(out + ((size_t)bin * 2 + c) * LN + (size_t)j * N + po) = r;
-    }
+    for (int r = 0; r < RPT; r++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if (r && !has[r]) continue;
+            const u64x2 v = res[r][c];
+            if (TILE)
+                s_tile[2 * r + c][KP * (threadIdx.x % TT) + threadIdx.x / TT] = v;  // standard offset inside the tile: KP (tau - tau0) + k
+            else
+                *reinterpret_cast<u64x2 *>(out + ((size_t)rows[r] * 2 + c) * LN + (size_t)j * N + po) = v;
+        }
     if (TILE) {
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 2; c++)
-            *reinterpret_cast<u64x2 *>(out + ((size_t)bin * 2 + c) * LN + (size_t)j * N + 2 * (std_pair + threadIdx.x)) = s_tile[c][threadIdx.x];
+        for (int r = 0; r < RPT; r++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                if (r && !has[r]) continue;
+                *reinterpret_cast<u64x2 *>(out + ((size_t)rows[r] * 2 + c) * LN + (size_t)j * N + 2 * (std_pair + threadIdx.x)) = s_tile[2 * r + c][threadIdx.x];
+            }
     }
 }
 void launch_relin_mac(const DevConsts *dc, u32 N, u32 L, const u64 *d01, size_t stride01, const u64 *dig, const u64 *key,
                       const u64 *mask, u64 *out, u32 nb, hipStream_t st, const u32 *out_map, size_t key_stride, u32 key_group,
                       u32 sigma_T, u32 sigma_kp, u32 mask_div)
 {
-    dim3 grid((N / 2 + TPB - 1) / TPB, L, nb);
     if (!key_group) key_group = 1;
     if (!mask_div) mask_div = 1;
     // sigma_T: out_map is the lane order of a register-blocked transform with sigma_T threads per slice, sigma_kp pairs per thread
     const bool tile = out_map && (sigma_kp == 16 || sigma_kp == 8) && sigma_T >= TPB / sigma_kp && sigma_T % (TPB / sigma_kp) == 0 &&
                       (N / 2) % TPB == 0;
     const int kp = tile ? (int)sigma_kp : 0;
-#define RM(M_, K_)                                                                                                              \
-    hipLaunchKernelGGL((relin_mac_kernel<M_, K_>), grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map, \
-                       key_stride, key_group, sigma_T, mask_div)
-    if (g_small_moduli) {
-        if (kp == 16) RM(true, 16); else if (kp == 8) RM(true, 8); else RM(true, 0);
+    // two rows per thread where at least two rows share a key (the column-accumulator path)
+    const bool two = g_small_moduli && nb >= 2 * key_group;
+    const u32 zrows = two ? ((nb + 2 * key_group - 1) / (2 * key_group)) * key_group : nb;
+    dim3 grid((N / 2 + TPB - 1) / TPB, L, zrows);
+#define RM(M_, K_, R_)                                                                                                              \
+    hipLaunchKernelGGL((relin_mac_kernel<M_, K_, R_>), grid, dim3(TPB), 0, st, dc, N, L, d01, stride01, dig, key, mask, out, out_map, \
+                       key_stride, key_group, sigma_T, mask_div, nb)
+    if (two) {
+        if (kp == 16) RM(true, 16, 2); else if (kp == 8) RM(true, 8, 2); else RM(true, 0, 2);
+    } else if (g_small_moduli) {
+        if (kp == 16) RM(true, 16, 1); else if (kp == 8) RM(true, 8, 1); else RM(true, 0, 1);
     } else {
-        if (kp == 16) RM(false, 16); else if (kp == 8) RM(false, 8); else RM(false, 0);
+        if (kp == 16) RM(false, 16, 1); else if (kp == 8) RM(false, 8, 1); else RM(false, 0, 1);
     }
 #undef RM
 }
