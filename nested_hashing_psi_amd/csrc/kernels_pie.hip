@@ -1078,40 +1078,54 @@ template <bool MAD>
 __global__ void __launch_bounds__(TPB) tensor_kernel(const DevConsts *dc, u32 N, u32 M, const u64 *__restrict__ e,
                                                      u64 *__restrict__ d)
 {
-    const u32 n = blockIdx.x * TPB + threadIdx.x;
+    // two adjacent coefficients per thread (16-byte lanes; the arrays are point-wise, any order): half the workgroups and waves of the
+    // one-coefficient form for the same bytes -- beside the other queue group's transforms that is what counts (r05, relin_mac likewise)
+    const u32 n = 2 * (blockIdx.x * TPB + threadIdx.x);
     if (n >= N) return;
     const u32 a = blockIdx.y, bin = blockIdx.z;
     const Mod m = dc->mod[a];
     const size_t MN = (size_t)M * N;
     const u64 *pe = e + (size_t)bin * 4 * MN + (size_t)a * N + n;
     u64 *pd = d + (size_t)bin * 3 * MN + (size_t)a * N + n;
-    u64 a0 = pe[0], a1 = pe[MN], b0 = pe[2 * MN], b1 = pe[3 * MN];
-    if (MAD) {
-        const u64 nq = neg_u(m.q), n2q = neg_u(2 * m.q), n4q = neg_u(4 * m.q);
-        a0 = csub_u(csub_u(a0, n4q), n2q), a1 = csub_u(csub_u(a1, n4q), n2q);
-        b0 = csub_u(csub_u(b0, n4q), n2q), b1 = csub_u(csub_u(b1, n4q), n2q);
-        const Split30 sa0 = split30(a0), sa1 = split30(a1), sb0 = split30(b0), sb1 = split30(b1);
-        ColAcc c = {0, 0, 0};
-        colacc_mac(c, sa0, sb0);
-        pd[0] = colacc_reduce<false>(c, m, nq);
-        c = ColAcc{0, 0, 0};
-        colacc_mac(c, sa0, sb1);
-        colacc_mac(c, sa1, sb0);
-        pd[MN] = colacc_reduce<false>(c, m, nq);
-        c = ColAcc{0, 0, 0};
-        colacc_mac(c, sa1, sb1);
-        pd[2 * MN] = colacc_reduce<false>(c, m, nq);
-        return;
+    const u64x2 va0 = *reinterpret_cast<const u64x2 *>(pe), va1 = *reinterpret_cast<const u64x2 *>(pe + MN),
+                vb0 = *reinterpret_cast<const u64x2 *>(pe + 2 * MN), vb1 = *reinterpret_cast<const u64x2 *>(pe + 3 * MN);
+    u64x2 r0, r1, r2;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        u64 a0 = k ? va0.y : va0.x, a1 = k ? va1.y : va1.x, b0 = k ? vb0.y : vb0.x, b1 = k ? vb1.y : vb1.x;
+        u64 d0, d1, d2;
+        if (MAD) {
+            const u64 nq = neg_u(m.q), n2q = neg_u(2 * m.q), n4q = neg_u(4 * m.q);
+            a0 = csub_u(csub_u(a0, n4q), n2q), a1 = csub_u(csub_u(a1, n4q), n2q);
+            b0 = csub_u(csub_u(b0, n4q), n2q), b1 = csub_u(csub_u(b1, n4q), n2q);
+            const Split30 sa0 = split30(a0), sa1 = split30(a1), sb0 = split30(b0), sb1 = split30(b1);
+            ColAcc c = {0, 0, 0};
+            colacc_mac(c, sa0, sb0);
+            d0 = colacc_reduce<false>(c, m, nq);
+            c = ColAcc{0, 0, 0};
+            colacc_mac(c, sa0, sb1);
+            colacc_mac(c, sa1, sb0);
+            d1 = colacc_reduce<false>(c, m, nq);
+            c = ColAcc{0, 0, 0};
+            colacc_mac(c, sa1, sb1);
+            d2 = colacc_reduce<false>(c, m, nq);
+        } else {
+            d0 = mulmod(a0, b0, m);
+            U128 x = mul128(a0, b1);
+            mac128(x, a1, b0);
+            d1 = reduce128(x, m);
+            d2 = mulmod(a1, b1, m);
+        }
+        if (k) r0.y = d0, r1.y = d1, r2.y = d2;
+        else r0.x = d0, r1.x = d1, r2.x = d2;
     }
-    pd[0] = mulmod(a0, b0, m);
-    U128 x = mul128(a0, b1);
-    mac128(x, a1, b0);
-    pd[MN] = reduce128(x, m);
-    pd[2 * MN] = mulmod(a1, b1, m);
+    *reinterpret_cast<u64x2 *>(pd) = r0;
+    *reinterpret_cast<u64x2 *>(pd + MN) = r1;
+    *reinterpret_cast<u64x2 *>(pd + 2 * MN) = r2;
 }
 void launch_tensor(const DevConsts *dc, u32 N, u32 M, const u64 *e, u64 *d, u32 nb, hipStream_t st)
 {
-    dim3 grid((N + TPB - 1) / TPB, M, nb);
+    dim3 grid((N / 2 + TPB - 1) / TPB, M, nb);   // (N is a power of two >= 8)
     if (g_small_moduli)
         hipLaunchKernelGGL(tensor_kernel<true>, grid, dim3(TPB), 0, st, dc, N, M, e, d);
     else
